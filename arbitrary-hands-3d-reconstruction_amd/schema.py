@@ -1,0 +1,144 @@
+"""Checkpoint schema of the ACR network (HRNet-W32 + ACR heads).
+
+This enumerates, from the topology alone, every tensor of the reference's
+``acr.model.ACR().state_dict()`` (names, shapes, role), so that the packer,
+the synthetic-checkpoint generator and the loader all agree on the key names
+a real ``wild.pkl`` carries (minus its ``module.`` prefix).
+
+Reference topology: acr/model.py:785-829 (make_baseline), :703-736
+(_make_transition_layer), :738-752 (_make_layer), :620-661 (_make_fuse_layers),
+:374-463 (SegmNet), :185-313 (heads).  Nothing here is executed on the
+reference; tests/test_schema.py pins the key list against a digest captured
+from the imported reference (tests/golden/schema_digest.json).
+"""
+from collections import OrderedDict
+
+STAGE_CFG = {
+    2: dict(modules=1, channels=[32, 64]),
+    3: dict(modules=4, channels=[32, 64, 128]),
+    4: dict(modules=3, channels=[32, 64, 128, 256]),
+}
+BLOCKS_PER_BRANCH = 4
+HEAD_CHANNELS = 64
+HEAD_BLOCKS = 2
+PARAMS_NUM = 109          # acr/result_parser.py:12-14
+TOWER_OUT = {1: 106, 2: 1, 3: 3, 4: 106}   # params, center, cam, prior (acr/model.py:185-202)
+
+
+def _conv(d, name, cout, cin, k, bias):
+    d[name + '.weight'] = (cout, cin, k, k)
+    if bias:
+        d[name + '.bias'] = (cout,)
+
+
+def _bn(d, name, c):
+    d[name + '.weight'] = (c,)
+    d[name + '.bias'] = (c,)
+    d[name + '.running_mean'] = (c,)
+    d[name + '.running_var'] = (c,)
+    d[name + '.num_batches_tracked'] = ()
+
+
+def _basic_block(d, p, c):
+    _conv(d, p + '.conv1', c, c, 3, False); _bn(d, p + '.bn1', c)
+    _conv(d, p + '.conv2', c, c, 3, False); _bn(d, p + '.bn2', c)
+
+
+def fuse_plan(nb, multi_scale):
+    """[(i, j, kind, [(cin, cout, relu)])] of a HighResolutionModule's fuse layers."""
+    return [(i, j) for i in range(nb if multi_scale else 1) for j in range(nb) if j != i]
+
+
+def state_dict_schema():
+    """OrderedDict key -> shape, in the reference's registration order."""
+    d = OrderedDict()
+    b = 'backbone.'
+    _conv(d, b + 'conv1', 64, 3, 3, False); _bn(d, b + 'bn1', 64)
+    _conv(d, b + 'conv2', 64, 64, 3, False); _bn(d, b + 'bn2', 64)
+    # layer1: 4 Bottlenecks, planes 64, expansion 4
+    for i in range(4):
+        p = b + 'layer1.%d' % i
+        cin = 64 if i == 0 else 256
+        _conv(d, p + '.conv1', 64, cin, 1, False); _bn(d, p + '.bn1', 64)
+        _conv(d, p + '.conv2', 64, 64, 3, False); _bn(d, p + '.bn2', 64)
+        _conv(d, p + '.conv3', 256, 64, 1, False); _bn(d, p + '.bn3', 256)
+        if i == 0:
+            _conv(d, p + '.downsample.0', 256, 64, 1, False); _bn(d, p + '.downsample.1', 256)
+    pre = [256]
+    for s in (2, 3, 4):
+        ch = STAGE_CFG[s]['channels']
+        # transition (registered before the stage)
+        t = b + 'transition%d' % (s - 1)
+        for i, c in enumerate(ch):
+            if i < len(pre):
+                if c != pre[i]:
+                    _conv(d, t + '.%d.0' % i, c, pre[i], 3, False); _bn(d, t + '.%d.1' % i, c)
+            else:
+                for j in range(i + 1 - len(pre)):
+                    cin = pre[-1]
+                    cout = c if j == i - len(pre) else cin
+                    _conv(d, t + '.%d.%d.0' % (i, j), cout, cin, 3, False)
+                    _bn(d, t + '.%d.%d.1' % (i, j), cout)
+        nb = len(ch)
+        for m in range(STAGE_CFG[s]['modules']):
+            p = b + 'stage%d.%d' % (s, m)
+            multi = not (s == 4 and m == STAGE_CFG[s]['modules'] - 1)
+            for br in range(nb):
+                for k in range(BLOCKS_PER_BRANCH):
+                    _basic_block(d, p + '.branches.%d.%d' % (br, k), ch[br])
+            for i in range(nb if multi else 1):
+                for j in range(nb):
+                    f = p + '.fuse_layers.%d.%d' % (i, j)
+                    if j > i:
+                        _conv(d, f + '.0', ch[i], ch[j], 1, False); _bn(d, f + '.1', ch[i])
+                    elif j < i:
+                        for k in range(i - j):
+                            cout = ch[i] if k == i - j - 1 else ch[j]
+                            _conv(d, f + '.%d.0' % k, cout, ch[j], 3, False)
+                            _bn(d, f + '.%d.1' % k, cout)
+        pre = ch
+    # part-segmentation head (acr/model.py:374-463)
+    u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
+    _conv(d, u + '.0', 16, 32, 3, True); _bn(d, u + '.1', 16)
+    _conv(d, u + '.3', 64, 16, 3, True); _bn(d, u + '.4', 64)
+    g = b + 'hand_segm.segm_head.segm_net.double_conv'
+    _conv(d, g + '.0', 33, 64, 3, True); _bn(d, g + '.1', 33)
+    _conv(d, g + '.3', 33, 33, 3, True)
+    # heads (acr/model.py:168-183)
+    for side in ('l', 'r'):
+        for t in (1, 2, 3, 4):
+            p = '%s_final_layers.%d' % (side, t)
+            _conv(d, p + '.0.0', HEAD_CHANNELS, 34, 3, True); _bn(d, p + '.0.1', HEAD_CHANNELS)
+            for k in range(HEAD_BLOCKS):
+                _basic_block(d, p + '.1.%d.0' % k, HEAD_CHANNELS)
+            _conv(d, p + '.2', TOWER_OUT[t], HEAD_CHANNELS, 1, True)
+    _conv(d, 'contact_layers.1.0', 256, 34, 3, True); _bn(d, 'contact_layers.1.1', 256)
+    d['contact_layers.2.weight'] = (1, 6, 256, 16, 1, 1)
+    d['contact_layers.3.weight'] = (1, 6, 256, 16, 1, 1)
+    _conv(d, 'contact_layers.4', PARAMS_NUM, 2 * PARAMS_NUM, 1, True)
+    _conv(d, 'contact_layers.5', PARAMS_NUM, 2 * PARAMS_NUM, 1, True)
+    _conv(d, 'cam_shape_layers.1.0', 64, 256, 1, True)
+    for k in (2, 3):
+        d['cam_shape_layers.%d.weight' % k] = (10, 1024)
+        d['cam_shape_layers.%d.bias' % k] = (10,)
+    # built by the reference but never called (acr/model.py:181,262-286); still in checkpoints
+    _conv(d, 'segmentation_layers.1.0', 256, 34, 3, True); _bn(d, 'segmentation_layers.1.1', 256)
+    _conv(d, 'segmentation_layers.2.0', 33, 256, 1, True)
+    return d
+
+
+def schema_digest():
+    import hashlib
+    h = hashlib.sha256()
+    d = state_dict_schema()
+    for k, s in d.items():
+        h.update(('%s:%s;' % (k, ','.join(map(str, s)))).encode())
+    n_params = 0
+    for k, s in d.items():
+        if k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'):
+            continue
+        n = 1
+        for v in s:
+            n *= v
+        n_params += n
+    return {'n_keys': len(d), 'n_params': n_params, 'sha256': h.hexdigest()}

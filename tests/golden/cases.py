@@ -1,0 +1,89 @@
+"""Seeded inputs shared by make_golden.py (authoring container, real reference) and the tests.
+
+Everything here is data generation with numpy PCG64 (identical on every box); no reference code.
+"""
+import numpy as np
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+# ---- decode cases (G4): head maps with planted center peaks -------------------------------------
+# name -> (left peak (y,x,score) or None, right peak or None)
+DECODE_CASES = {
+    'both_near': ((20, 30, 0.9), (25, 40, 0.8)),
+    'both_far': ((5, 6, 0.7), (50, 55, 0.95)),
+    'both_dist32': ((10, 10, 0.6), (10, 42, 0.6)),        # distance == 32 exactly -> prior kept
+    'left_only': ((33, 12, 0.5), None),
+    'right_only': (None, (63, 63, 0.36)),
+    'none': (None, None),
+    'edge_corner': ((0, 0, 0.9), (63, 0, 0.9)),
+    'below_thresh': ((12, 12, 0.35), (40, 40, 0.3499)),   # strict > 0.35
+}
+
+
+def decode_maps(name):
+    """Head-map dict (float32, NCHW, B=1) for a decode case."""
+    lp, rp = DECODE_CASES[name]
+    g = rng(abs(hash_name(name)))
+    m = {}
+    for s, pk in (('l', lp), ('r', rp)):
+        c = g.uniform(-0.2, 0.2, (1, 1, 64, 64)).astype(np.float32)
+        if pk is not None:
+            c[0, 0, pk[0], pk[1]] = pk[2]
+        m[s + '_center_map'] = c
+        m[s + '_params_maps'] = g.normal(0, 0.6, (1, 109, 64, 64)).astype(np.float32)
+        m[s + '_prior_maps'] = g.normal(0, 0.3, (1, 106, 64, 64)).astype(np.float32)
+    return m
+
+
+def hash_name(name):
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % (2 ** 31)
+    return h
+
+
+# ---- rotation KATs (G5) ---------------------------------------------------------------------------
+def rot6d_inputs():
+    g = rng(55)
+    x = g.normal(0, 1, (40, 6)).astype(np.float32)
+    x[0] = [1, 0, 0, 1, 0, 0]                 # identity: b1=(1,0,0) a2=(0,1,0) interleaved
+    x[1] = [1, 1e-4, 0, 1, 1e-4, 0]           # near identity
+    x[2] = [-1, 0, 0, -1, 0, 1]               # rotation by pi about z
+    x[3] = [-1, 1e-3, 0, -1, 0, 1]            # near pi
+    x[4] = [1, 2, 1, 2, 1, 2]                 # parallel b1, a2 (degenerate)
+    x[5] = [0, 0, 0, 0, 0, 0]                 # zero
+    x[6] = [1, 0, 0, 0, 0, 1]                 # R[2,2] < eps branch
+    x[7] = [0, 1, 1, 0, 0, 0]
+    x[8] = [-1, 0, 0, 1, 0, 0]
+    x[9] = [0, -1, -1, 0, 0, 0]
+    return x
+
+
+# ---- MANO cases (G6) ------------------------------------------------------------------------------
+def mano_inputs(n, seed):
+    g = rng(700 + seed)
+    poses = g.normal(0, 0.4, (n, 48)).astype(np.float32)
+    betas = g.normal(0, 1.0, (n, 10)).astype(np.float32)
+    if n >= 1:
+        poses[0] = 0
+        betas[0] = 0
+    if n >= 2:
+        poses[1] = g.normal(0, 1.5, 48).astype(np.float32)   # large pose
+    return poses, betas
+
+
+def proj_inputs(n, seed):
+    g = rng(900 + seed)
+    cam = np.stack([g.uniform(0.5, 2.0, n), g.uniform(-0.5, 0.5, n), g.uniform(-0.5, 0.5, n)], 1).astype(np.float32)
+    offsets = np.tile(np.array([[1920, 1920, 0, 0, 0, 0, 420, 0, 420, 0]], np.float32), (n, 1))
+    return cam, offsets
+
+
+def sub(t, max_elems=4096):
+    """Deterministic strided subsample of an array's flattened view + fp64 checksums."""
+    a = np.asarray(t, dtype=np.float32).reshape(-1)
+    step = max(1, a.size // max_elems)
+    return a[::step][:max_elems].copy(), np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
