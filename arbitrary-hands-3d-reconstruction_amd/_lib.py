@@ -1,0 +1,101 @@
+"""ctypes binding of libacrmi.so (include/acrmi.h).  No CPU fallback: if the HIP library is
+missing or fails to load, every entry point raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libacrmi.so')
+
+OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL = range(1, 9)
+SLOT = 176
+SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
+E_INVAL, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
+
+
+class BufferDesc(C.Structure):
+    _fields_ = [('h', C.c_int32), ('w', C.c_int32), ('cs', C.c_int32), ('persistent', C.c_int32)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', C.c_int32),
+                ('in_buf', C.c_int32), ('out_buf', C.c_int32), ('res_buf', C.c_int32),
+                ('in_coff', C.c_int32), ('out_coff', C.c_int32), ('res_coff', C.c_int32),
+                ('cin', C.c_int32), ('cout', C.c_int32),
+                ('ksize', C.c_int32), ('stride', C.c_int32), ('relu', C.c_int32), ('groups', C.c_int32),
+                ('w_off', C.c_int64), ('b_off', C.c_int64),
+                ('bias_per_frame', C.c_int32), ('aux_buf', C.c_int32), ('nterms', C.c_int32),
+                ('term_buf', C.c_int32 * 4), ('term_coff', C.c_int32 * 4), ('term_shift', C.c_int32 * 4),
+                ('w_off2', C.c_int64), ('b_off2', C.c_int64), ('w_off3', C.c_int64),
+                ('flags', C.c_int32), ('reserved', C.c_int32)]
+
+
+class HeadLayout(C.Structure):
+    _fields_ = [('center_buf', C.c_int32 * 2), ('params_buf', C.c_int32 * 2), ('prior_buf', C.c_int32 * 2),
+                ('segm_buf', C.c_int32), ('backbone_buf', C.c_int32)]
+
+
+EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy', 'acrmi_load_weights',
+           'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
+           'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
+           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops']
+
+_lib = None
+
+
+class AcrmiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libacrmi.so (built in-tree by build.py).  Raises if it is absent: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AcrmiError('libacrmi.so not built: run `python __graft_entry__.py build` (needs hipcc). '
+                         'The ACR path has no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32p, u8p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    L.acrmi_version.restype = C.c_int
+    L.acrmi_last_error.restype = C.c_char_p
+    L.acrmi_last_error.argtypes = [vp]
+    L.acrmi_create.argtypes = [C.POINTER(vp), i32]
+    L.acrmi_destroy.argtypes = [vp]
+    L.acrmi_destroy.restype = None
+    L.acrmi_load_weights.argtypes = [vp, vp, C.c_size_t]
+    L.acrmi_set_program.argtypes = [vp, C.POINTER(BufferDesc), i32, C.POINTER(Op), i32, C.POINTER(HeadLayout), i32]
+    L.acrmi_load_mano.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.acrmi_backbone_heads.argtypes = [vp, u8p, i32, vp]
+    L.acrmi_buffer_ptr.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.acrmi_buffer_ptr.restype = vp
+    L.acrmi_decode.argtypes = [vp, i32, f32p, vp]
+    L.acrmi_decode_maps.argtypes = [f32p, f32p, i32, f32p, f32p, i32, f32p, f32p, i32, i32, f32p, vp]
+    L.acrmi_mano.argtypes = [vp, f32p, i32, f32p, i32, vp, i32, i32, f32p, f32p, f32p, f32p, i32, f32p, f32p, f32p,
+                             f32p, vp]
+    L.acrmi_forward.argtypes = [vp, u8p, i32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp]
+    L.acrmi_conv2d.argtypes = [f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, i32, f32p, i32, i32, f32p, i32, i32,
+                               i32, i32, i32, i32, i32, vp]
+    L.acrmi_u8norm.argtypes = [u8p, i32, f32p, vp]
+    L.acrmi_bilinear2x.argtypes = [f32p, i32, i32, i32, i32, i32, f32p, i32, vp]
+    L.acrmi_fuse_sum.argtypes = [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, f32p, i32,
+                                 i32, vp]
+    L.acrmi_attpool.argtypes = [f32p, i32, f32p, i32, i32, i32, f32p, f32p, vp]
+    L.acrmi_profile_ops.argtypes = [vp, u8p, i32, vp, i32, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr'):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    """Maps the C error codes onto the exceptions the reference raises (ValueError for bad
+    configuration/arguments, RuntimeError otherwise)."""
+    if rc >= 0:
+        return rc
+    msg = lib().acrmi_last_error(ctx)
+    msg = msg.decode() if msg else 'acrmi error %d' % rc
+    if rc == E_INVAL:
+        raise ValueError(msg)
+    raise AcrmiError(msg)

@@ -1,0 +1,431 @@
+// libacrmi.so: context, program replay and the C ABI declared in include/acrmi.h.
+#include "../../include/acrmi.h"
+#include "kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace acrmi;
+
+struct acrmi_ctx {
+  int device = 0;
+  std::string err;
+  float* weights = nullptr;
+  size_t n_weights = 0;
+  std::vector<acrmi_buffer_desc> bufs;
+  std::vector<float*> buf_ptr;
+  std::vector<acrmi_op> ops;
+  acrmi_head_layout heads{};
+  bool have_program = false;
+  int max_batch = 0;
+  float* att_ws = nullptr;      // attention-pool workspace
+  size_t att_ws_floats = 0;
+  float* img_f32 = nullptr;     // unused (U8NORM writes into a program buffer)
+  ManoTables mano[2]{};
+  bool have_mano[2] = {false, false};
+  std::vector<float*> mano_allocs;
+};
+
+static std::string g_err;
+
+static int fail(acrmi_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_err = buf;
+  return code;
+}
+#define HIPCHK(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(c, ACRMI_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" {
+
+int acrmi_version(void) { return ACRMI_VERSION; }
+
+const char* acrmi_last_error(const acrmi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int acrmi_create(acrmi_ctx** out, int device) {
+  if (!out) return fail(nullptr, ACRMI_EINVAL, "acrmi_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, ACRMI_EHIP, "acrmi_create: no HIP device (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(nullptr, ACRMI_EINVAL, "acrmi_create: device %d of %d", device, n);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+  acrmi_ctx* c = new acrmi_ctx();
+  c->device = device;
+  *out = c;
+  return ACRMI_OK;
+}
+
+static void free_program(acrmi_ctx* c) {
+  for (float* p : c->buf_ptr)
+    if (p) (void)hipFree(p);
+  c->buf_ptr.clear();
+  c->bufs.clear();
+  c->ops.clear();
+  if (c->att_ws) (void)hipFree(c->att_ws);
+  c->att_ws = nullptr;
+  c->have_program = false;
+}
+
+void acrmi_destroy(acrmi_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_program(c);
+  if (c->weights) (void)hipFree(c->weights);
+  for (float* p : c->mano_allocs) (void)hipFree(p);
+  delete c;
+}
+
+int acrmi_load_weights(acrmi_ctx* c, const float* blob, size_t n) {
+  if (!c || !blob || n == 0) return fail(c, ACRMI_EINVAL, "acrmi_load_weights: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->weights) (void)hipFree(c->weights);
+  c->weights = nullptr;
+  HIPCHK(c, hipMalloc(&c->weights, n * sizeof(float)));
+  HIPCHK(c, hipMemcpy(c->weights, blob, n * sizeof(float), hipMemcpyHostToDevice));
+  c->n_weights = n;
+  return ACRMI_OK;
+}
+
+static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s) {
+  auto ptr = [&](int id) -> float* { return id >= 0 ? c->buf_ptr[id] : nullptr; };
+  auto desc = [&](int id) -> const acrmi_buffer_desc& { return c->bufs[id]; };
+  switch (op.kind) {
+    case ACRMI_OP_U8NORM: {
+      const auto& d = desc(op.out_buf);
+      HIPCHK(c, launch_u8norm(img, (long)B * d.h * d.w, ptr(op.out_buf), s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_CONV: {
+      const auto& di = desc(op.in_buf);
+      const auto& dout = desc(op.out_buf);
+      ConvArgs a{};
+      a.in = ptr(op.in_buf);
+      a.w = c->weights + op.w_off;
+      a.bias = op.bias_per_frame ? ptr(op.aux_buf) : c->weights + op.b_off;
+      a.res = ptr(op.res_buf);
+      a.out = ptr(op.out_buf);
+      a.B = B; a.H = di.h; a.W = di.w; a.Ho = dout.h; a.Wo = dout.w;
+      a.in_cs = di.cs; a.in_coff = op.in_coff; a.Cin = op.cin;
+      a.out_cs = dout.cs; a.out_coff = op.out_coff; a.Cout = op.cout;
+      a.res_cs = op.res_buf >= 0 ? desc(op.res_buf).cs : 0; a.res_coff = op.res_coff;
+      a.ks = op.ksize; a.stride = op.stride; a.relu = op.relu; a.groups = op.groups;
+      a.cin8 = (op.cin + 7) / 8;
+      a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
+      a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
+      HIPCHK(c, launch_conv(a, s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_FUSESUM: {
+      const auto& dout = desc(op.out_buf);
+      FuseArgs f{};
+      f.nterms = op.nterms; f.B = B; f.H = dout.h; f.W = dout.w; f.C = op.cout; f.out_cs = dout.cs; f.relu = op.relu;
+      f.out = ptr(op.out_buf) + op.out_coff;
+      for (int t = 0; t < op.nterms; ++t) {
+        f.term[t] = ptr(op.term_buf[t]) + op.term_coff[t];
+        f.cs[t] = desc(op.term_buf[t]).cs;
+        f.shift[t] = op.term_shift[t];
+      }
+      HIPCHK(c, launch_fuse_sum(f, s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_BILINEAR2X: {
+      const auto& di = desc(op.in_buf);
+      HIPCHK(c, launch_bilinear2x(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
+                                  desc(op.out_buf).cs, op.out_coff, s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_POW11: {
+      const auto& d = desc(op.out_buf);
+      HIPCHK(c, launch_pow11(ptr(op.out_buf), (long)B * d.h * d.w, d.cs, op.out_coff, s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_ATTPOOL: {
+      const auto& ds = desc(op.in_buf);     // segm logits
+      const auto& df = desc(op.res_buf);    // features
+      float* stats = c->att_ws;
+      float* part = c->att_ws + (size_t)c->max_batch * 16 * 32 * 2;
+      HIPCHK(c, launch_attpool(ptr(op.in_buf), ds.cs, ptr(op.res_buf) + op.res_coff, df.cs, op.cin, B, df.h, df.w,
+                               stats, part, ptr(op.out_buf), s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_PAREBIAS: {
+      PareArgs p{};
+      p.pooled = ptr(op.in_buf);
+      p.lc_w = c->weights + op.w_off;
+      p.lin_w = c->weights + op.w_off2;
+      p.lin_b = c->weights + op.b_off2;
+      p.mix_wp = c->weights + op.w_off3;
+      p.mix_b = c->weights + op.b_off;
+      p.out = ptr(op.out_buf);
+      p.B = B; p.C = op.cin; p.part0 = op.flags; p.out_stride = desc(op.out_buf).cs;
+      HIPCHK(c, launch_parebias(p, s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_COORDFILL: {
+      const auto& d = desc(op.out_buf);
+      HIPCHK(c, launch_coordfill(ptr(op.out_buf), c->max_batch, d.h, d.w, d.cs, op.out_coff, s));
+      return ACRMI_OK;
+    }
+    default:
+      return fail(c, ACRMI_EINVAL, "unknown op kind %d", op.kind);
+  }
+}
+
+int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, const acrmi_op* ops, int n_ops,
+                      const acrmi_head_layout* heads, int max_batch) {
+  if (!c || !bufs || !ops || !heads || n_bufs <= 0 || n_ops <= 0 || max_batch <= 0)
+    return fail(c, ACRMI_EINVAL, "acrmi_set_program: bad arguments");
+  if (!c->weights) return fail(c, ACRMI_ESTATE, "acrmi_set_program: load weights first");
+  HIPCHK(c, hipSetDevice(c->device));
+  free_program(c);
+  c->bufs.assign(bufs, bufs + n_bufs);
+  c->ops.assign(ops, ops + n_ops);
+  c->heads = *heads;
+  c->max_batch = max_batch;
+  c->buf_ptr.assign(n_bufs, nullptr);
+  for (int i = 0; i < n_bufs; ++i) {
+    const auto& d = bufs[i];
+    if (d.h <= 0 || d.w <= 0 || d.cs <= 0 || d.cs % 4) return fail(c, ACRMI_EINVAL, "buffer %d: bad geometry", i);
+    const size_t bytes = (size_t)max_batch * d.h * d.w * d.cs * sizeof(float);
+    hipError_t e = hipMalloc(&c->buf_ptr[i], bytes);
+    if (e != hipSuccess) return fail(c, ACRMI_ENOMEM, "hipMalloc(%zu) for buffer %d: %s", bytes, i, hipGetErrorString(e));
+    HIPCHK(c, hipMemset(c->buf_ptr[i], 0, bytes));
+  }
+  for (int i = 0; i < n_ops; ++i) {
+    const acrmi_op& op = ops[i];
+    const int ids[4] = {op.in_buf, op.out_buf, op.res_buf, op.aux_buf};
+    for (int id : ids)
+      if (id >= n_bufs) return fail(c, ACRMI_EINVAL, "op %d references buffer %d of %d", i, id, n_bufs);
+    if (op.kind == ACRMI_OP_CONV && (op.in_coff % 4 || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2))
+      return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
+  }
+  c->att_ws_floats = attpool_ws_floats(max_batch, 320);
+  HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
+  c->have_program = true;
+  // init-time ops (constants that live in persistent buffers)
+  for (const acrmi_op& op : c->ops)
+    if (op.kind == ACRMI_OP_COORDFILL) {
+      int r = run_op(c, op, nullptr, max_batch, nullptr);
+      if (r) return r;
+    }
+  HIPCHK(c, hipDeviceSynchronize());
+  return ACRMI_OK;
+}
+
+int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float* shapedirs, const float* posedirs,
+                    const float* J_regressor, const float* weights, const float* hands_mean) {
+  if (!c || side < 0 || side > 1 || !v_template || !shapedirs || !posedirs || !J_regressor || !weights || !hands_mean)
+    return fail(c, ACRMI_EINVAL, "acrmi_load_mano: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  constexpr int NV3 = 2334;
+  std::vector<float> sd_t((size_t)10 * NV3), pd_t((size_t)135 * NV3);
+  for (int i = 0; i < NV3; ++i) {
+    for (int k = 0; k < 10; ++k) sd_t[(size_t)k * NV3 + i] = shapedirs[(size_t)i * 10 + k];
+    for (int k = 0; k < 135; ++k) pd_t[(size_t)k * NV3 + i] = posedirs[(size_t)i * 135 + k];
+  }
+  auto up = [&](const float* h, size_t n, const float** dst) -> int {
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n * sizeof(float)));
+    c->mano_allocs.push_back(d);
+    HIPCHK(c, hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
+    *dst = d;
+    return ACRMI_OK;
+  };
+  ManoTables& t = c->mano[side];
+  int r;
+  if ((r = up(v_template, NV3, &t.v_template))) return r;
+  if ((r = up(sd_t.data(), sd_t.size(), &t.shapedirs_t))) return r;
+  if ((r = up(pd_t.data(), pd_t.size(), &t.posedirs_t))) return r;
+  if ((r = up(J_regressor, 16 * 778, &t.jreg))) return r;
+  if ((r = up(weights, 778 * 16, &t.weights))) return r;
+  if ((r = up(hands_mean, 45, &t.hands_mean))) return r;
+  c->have_mano[side] = true;
+  return ACRMI_OK;
+}
+
+int acrmi_backbone_heads(acrmi_ctx* c, const uint8_t* img, int B, void* stream) {
+  if (!c || !img) return fail(c, ACRMI_EINVAL, "acrmi_backbone_heads: bad arguments");
+  if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_heads: no program");
+  if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  for (const acrmi_op& op : c->ops) {
+    if (op.kind == ACRMI_OP_COORDFILL) continue;
+    int r = run_op(c, op, img, B, (hipStream_t)stream);
+    if (r) return r;
+  }
+  return ACRMI_OK;
+}
+
+int acrmi_profile_ops(acrmi_ctx* c, const uint8_t* img, int B, float* ms_out, int n_ms, void* stream) {
+  if (!c || !img || !ms_out) return fail(c, ACRMI_EINVAL, "acrmi_profile_ops: bad arguments");
+  if (!c->have_program) return fail(c, ACRMI_ESTATE, "no program");
+  const int n = (int)c->ops.size();
+  if (n_ms < n) return fail(c, ACRMI_EINVAL, "ms_out too small (%d < %d)", n_ms, n);
+  hipStream_t s = (hipStream_t)stream;
+  int r = acrmi_backbone_heads(c, img, B, stream);
+  if (r) return r;
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+  HIPCHK(c, hipEventRecord(ev[0], s));
+  for (int i = 0; i < n; ++i) {
+    if (c->ops[i].kind != ACRMI_OP_COORDFILL) {
+      r = run_op(c, c->ops[i], img, B, s);
+      if (r) return r;
+    }
+    HIPCHK(c, hipEventRecord(ev[i + 1], s));
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) HIPCHK(c, hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return n;
+}
+
+void* acrmi_buffer_ptr(acrmi_ctx* c, int buf, int* h, int* w, int* cs) {
+  if (!c || !c->have_program || buf < 0 || buf >= (int)c->bufs.size()) return nullptr;
+  if (h) *h = c->bufs[buf].h;
+  if (w) *w = c->bufs[buf].w;
+  if (cs) *cs = c->bufs[buf].cs;
+  return c->buf_ptr[buf];
+}
+
+int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs, const float* l_params,
+                      const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
+                      int B, float* slots, void* stream) {
+  if (!l_center || !r_center || !l_params || !r_params || !l_prior || !r_prior || !slots || B <= 0)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_decode_maps: bad arguments");
+  DecodeArgs d{};
+  d.center[0] = l_center; d.center[1] = r_center; d.center_cs = center_cs;
+  d.params[0] = l_params; d.params[1] = r_params; d.params_cs = params_cs;
+  d.prior[0] = l_prior; d.prior[1] = r_prior; d.prior_cs = prior_cs;
+  d.B = B; d.slots = slots;
+  hipError_t e = launch_decode(d, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "decode launch: %s", hipGetErrorString(e));
+  return ACRMI_OK;
+}
+
+int acrmi_decode(acrmi_ctx* c, int B, float* slots, void* stream) {
+  if (!c || !slots) return fail(c, ACRMI_EINVAL, "acrmi_decode: bad arguments");
+  if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_decode: no program");
+  if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  const acrmi_head_layout& h = c->heads;
+  int r = acrmi_decode_maps(c->buf_ptr[h.center_buf[0]], c->buf_ptr[h.center_buf[1]], c->bufs[h.center_buf[0]].cs,
+                            c->buf_ptr[h.params_buf[0]], c->buf_ptr[h.params_buf[1]], c->bufs[h.params_buf[0]].cs,
+                            c->buf_ptr[h.prior_buf[0]], c->buf_ptr[h.prior_buf[1]], c->bufs[h.prior_buf[0]].cs, B,
+                            slots, stream);
+  if (r) c->err = g_err;
+  return r;
+}
+
+int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* betas, int beta_stride,
+               const int32_t* side, int H, int center_idx, float* verts, float* joints, float* center,
+               const float* cam, int cam_stride, const float* offsets, float* verts_camed, float* pj2d,
+               float* pj2d_org, void* stream) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_mano: ctx is NULL");
+  if (H == 0) return ACRMI_OK;    // ManoLayer accepts N == 0 (acr/mano_wrapper.py:43 comment)
+  if (H < 0 || !poses || !betas || !verts || !joints || center_idx >= 21)
+    return fail(c, ACRMI_EINVAL, "acrmi_mano: bad arguments");
+  if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_mano: MANO tables not loaded");
+  ManoArgs m{};
+  m.t[0] = c->mano[0]; m.t[1] = c->mano[1];
+  m.poses = poses; m.pose_stride = pose_stride; m.betas = betas; m.beta_stride = beta_stride;
+  m.side = side; m.H = H; m.center_idx = center_idx;
+  m.verts = verts; m.joints = joints; m.center = center;
+  m.cam = cam; m.cam_stride = cam_stride; m.offsets = offsets; m.off_div = 1;
+  m.verts_camed = verts_camed; m.pj2d = pj2d; m.pj2d_org = pj2d_org;
+  HIPCHK(c, launch_mano(m, (hipStream_t)stream));
+  return ACRMI_OK;
+}
+
+int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets, float* slots, float* verts,
+                  float* joints, float* verts_camed, float* pj2d, float* pj2d_org, void* stream) {
+  if (!c || !slots || !verts || !joints) return fail(c, ACRMI_EINVAL, "acrmi_forward: bad arguments");
+  if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_forward: MANO tables not loaded");
+  int r = acrmi_backbone_heads(c, img, B, stream);
+  if (r) return r;
+  r = acrmi_decode(c, B, slots, stream);
+  if (r) return r;
+  ManoArgs m{};
+  m.t[0] = c->mano[0]; m.t[1] = c->mano[1];
+  m.poses = slots + ACRMI_SLOT_POSES; m.pose_stride = ACRMI_SLOT;
+  m.betas = slots + ACRMI_SLOT_BETAS; m.beta_stride = ACRMI_SLOT;
+  m.side = nullptr; m.H = 2 * B; m.center_idx = 9;
+  m.verts = verts; m.joints = joints; m.center = nullptr;
+  const bool proj = verts_camed || pj2d || pj2d_org;
+  m.cam = proj ? slots + ACRMI_SLOT_CAM : nullptr; m.cam_stride = ACRMI_SLOT;
+  m.offsets = offsets; m.off_div = 2;
+  m.verts_camed = verts_camed; m.pj2d = pj2d; m.pj2d_org = pj2d_org;
+  HIPCHK(c, launch_mano(m, (hipStream_t)stream));
+  return ACRMI_OK;
+}
+
+// ---- stand-alone operators -------------------------------------------------------------------------
+int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
+                 const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff, float* out,
+                 int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups, void* stream) {
+  if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
+  if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: input channel stride/offset must be multiples of 4");
+  ConvArgs a{};
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = res; a.out = out;
+  a.B = B; a.H = H; a.W = W;
+  const int pad = ksize / 2;
+  a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+  a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = cin;
+  a.out_cs = out_cs; a.out_coff = out_coff; a.Cout = cout;
+  a.res_cs = res_cs; a.res_coff = res_coff;
+  a.ks = ksize; a.stride = stride; a.relu = relu; a.groups = groups;
+  a.cin8 = (cin + 7) / 8;
+  a.n_tiles = cout <= 32 ? 1 : ((cout + 63) / 64) * 2;
+  a.bias_fstride = bias_frame_stride;
+  hipError_t e = launch_conv(a, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
+  return ACRMI_OK;
+}
+
+int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream) {
+  if (!img || !out || n_pixels <= 0) return fail(nullptr, ACRMI_EINVAL, "acrmi_u8norm: bad arguments");
+  hipError_t e = launch_u8norm(img, n_pixels, out, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "u8norm: %s", hipGetErrorString(e));
+}
+
+int acrmi_bilinear2x(const float* in, int B, int H, int W, int in_cs, int C, float* out, int out_cs, void* stream) {
+  if (!in || !out || B <= 0 || H < 2 || W < 2 || C % 4 || in_cs % 4 || out_cs % 4)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_bilinear2x: bad arguments");
+  hipError_t e = launch_bilinear2x(in, B, H, W, in_cs, 0, C, out, out_cs, 0, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "bilinear2x: %s", hipGetErrorString(e));
+}
+
+int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, const int* term_shift, int B, int H,
+                   int W, int C, float* out, int out_cs, int relu, void* stream) {
+  if (nterms < 1 || nterms > 4 || !terms || !term_cs || !term_shift || !out || C % 4)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_fuse_sum: bad arguments");
+  FuseArgs f{};
+  f.nterms = nterms; f.B = B; f.H = H; f.W = W; f.C = C; f.out = out; f.out_cs = out_cs; f.relu = relu;
+  for (int t = 0; t < nterms; ++t) { f.term[t] = terms[t]; f.cs[t] = term_cs[t]; f.shift[t] = term_shift[t]; }
+  hipError_t e = launch_fuse_sum(f, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "fuse_sum: %s", hipGetErrorString(e));
+}
+
+int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* ws,
+                  float* pooled, void* stream) {
+  if (!segm || !feat || !ws || !pooled || B <= 0) return fail(nullptr, ACRMI_EINVAL, "acrmi_attpool: bad arguments");
+  float* part = ws + (size_t)B * 16 * 32 * 2;
+  hipError_t e = launch_attpool(segm, segm_cs, feat, feat_cs, C, B, 128, 128, ws, part, pooled, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "attpool: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"

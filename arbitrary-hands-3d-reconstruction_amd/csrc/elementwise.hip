@@ -1,0 +1,129 @@
+// HBM-bound helper kernels of the ACR path: 16-byte coalesced accesses, grid-stride loops.
+#include "kernels.h"
+
+namespace acrmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(long n, int block) {
+  long g = (n + block - 1) / block;
+  const long cap = 256L * 32;   // 256 CUs x 32 workgroups is plenty for a grid-stride loop
+  return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+// uint8 RGB -> fp32 (x/255)*2-1, 4th channel zero (acr/model.py:832 + acr/utils.py:226-231 without the NCHW copy)
+__global__ __launch_bounds__(256) void u8norm_kernel(const uint8_t* __restrict__ img, long n_pixels,
+                                                     f32x4* __restrict__ out) {
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < n_pixels; p += (long)gridDim.x * 256) {
+    const uint8_t* q = img + p * 3;
+    f32x4 v;
+    v[0] = ((float)q[0] / 255.f) * 2.0f - 1.0f;
+    v[1] = ((float)q[1] / 255.f) * 2.0f - 1.0f;
+    v[2] = ((float)q[2] / 255.f) * 2.0f - 1.0f;
+    v[3] = 0.f;
+    out[p] = v;
+  }
+}
+hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(u8norm_kernel, dim3(grid_for(n_pixels, 256)), dim3(256), 0, s, img, n_pixels,
+                     reinterpret_cast<f32x4*>(out));
+  return hipGetLastError();
+}
+
+// bilinear x2, align_corners=True (F.interpolate at acr/model.py:432): src = dst*(in-1)/(out-1)
+__global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict__ in, int B, int H, int W, int in_cs,
+                                                         int in_coff, int C4, float* __restrict__ out, int out_cs,
+                                                         int out_coff) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
+  const long n = (long)B * Ho * Wo * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c4 = i % C4;
+    long p = i / C4;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const float fy = sh * oy, fx = sw * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = in + (size_t)b * H * W * in_cs + in_coff + c4 * 4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * in_cs);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * in_cs);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * in_cs);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * in_cs);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_coff + c4 * 4) = r;
+  }
+}
+hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,
+                             int out_cs, int out_coff, hipStream_t s) {
+  const long n = (long)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(bilinear2x_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, in, B, H, W, in_cs, in_coff, C / 4,
+                     out, out_cs, out_coff);
+  return hipGetLastError();
+}
+
+// HR-module fusion: out = [relu](t0 + up(t1) + ...), summed in the reference's order (acr/model.py:677-684)
+__global__ __launch_bounds__(256) void fuse_sum_kernel(const FuseArgs a) {
+  const int C4 = a.C / 4;
+  const long n = (long)a.B * a.H * a.W * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c4 = i % C4;
+    long p = i / C4;
+    const int x = p % a.W;
+    p /= a.W;
+    const int y = p % a.H;
+    const int b = p / a.H;
+    f32x4 acc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < a.nterms) {
+        const int sh = a.shift[t];
+        const int h = a.H >> sh, w = a.W >> sh;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            a.term[t] + (((size_t)b * h + (y >> sh)) * w + (x >> sh)) * a.cs[t] + c4 * 4);
+        if (t == 0) acc = v; else acc += v;
+      }
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.H + y) * a.W + x) * a.out_cs + c4 * 4) = acc;
+  }
+}
+hipError_t launch_fuse_sum(const FuseArgs& a, hipStream_t s) {
+  const long n = (long)a.B * a.H * a.W * (a.C / 4);
+  hipLaunchKernelGGL(fuse_sum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// cam scale channel: x := 1.1 ** x (acr/model.py:95-96)
+__global__ __launch_bounds__(256) void pow11_kernel(float* buf, long n_pixels, int cs, int ch) {
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < n_pixels; p += (long)gridDim.x * 256)
+    buf[p * cs + ch] = powf(1.1f, buf[p * cs + ch]);
+}
+hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s) {
+  hipLaunchKernelGGL(pow11_kernel, dim3(grid_for(n_pixels, 256)), dim3(256), 0, s, buf, n_pixels, cs, ch);
+  return hipGetLastError();
+}
+
+// coord maps (acr/model.py:340-369): channel coff = x (along W), coff+1 = y (along H), i/(size-1)*2-1
+__global__ __launch_bounds__(256) void coordfill_kernel(float* buf, int B, int H, int W, int cs, int coff) {
+  const long n = (long)B * H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += (long)gridDim.x * 256) {
+    const int x = p % W, y = (p / W) % H;
+    buf[p * cs + coff] = ((float)x / (float)(W - 1)) * 2.f - 1.f;
+    buf[p * cs + coff + 1] = ((float)y / (float)(H - 1)) * 2.f - 1.f;
+  }
+}
+hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, hipStream_t s) {
+  hipLaunchKernelGGL(coordfill_kernel, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, s, buf, B, H, W, cs, coff);
+  return hipGetLastError();
+}
+
+}  // namespace acrmi

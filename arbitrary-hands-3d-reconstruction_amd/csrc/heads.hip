@@ -1,0 +1,328 @@
+// ACR head micro-kernels: part-attention pooling (MFMA), pare bias, center decode.
+#include "kernels.h"
+#include "../../include/acrmi.h"
+
+namespace acrmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// Part attention (acr/model.py:103-113,126-136): pooled[b][p][c] = sum_pix softmax_pix(logit[b][p])[pix] * feat[b][pix][c]
+// logits = segm channels 1..32 at even pixels (nearest /2 of the 256x256 map, acr/model.py:126-128).
+// Pass 1: per (frame, 1/16 of the pixels) online max / sum-exp per part, lanes <-> parts (128 B coalesced rows).
+// Pass 2: per (frame, 1/8 of the pixels): GEMM [32 parts x K pixels] x [K x C] on v_mfma_f32_32x32x2_f32,
+//         A = exp(logit - max) computed on the fly, B = feature rows straight from HBM (read exactly once).
+// Pass 3: deterministic reduction of the partial tiles, scaled by 1/sum-exp.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_SCHUNKS = 16;
+
+__global__ __launch_bounds__(256) void att_stats_kernel(const float* __restrict__ segm, int segm_cs, int H, int W,
+                                                        float* __restrict__ ws) {
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int part = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int npix = H * W, per = npix / ATT_SCHUNKS;
+  const float* base = segm + (size_t)b * (2 * H) * (2 * W) * segm_cs + 1 + part;
+  float m = -INFINITY, s = 0.f;
+  for (int q = chunk * per + grp; q < (chunk + 1) * per; q += 8) {
+    const int y = q / W, x = q % W;
+    const float v = base[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs];
+    const float nm = fmaxf(m, v);
+    s = s * expf(m - nm) + expf(v - nm);
+    m = nm;
+  }
+  __shared__ float sm[8][32], ss[8][32];
+  sm[grp][part] = m;
+  ss[grp][part] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float M = sm[0][part];
+    for (int g = 1; g < 8; ++g) M = fmaxf(M, sm[g][part]);
+    float S = 0.f;
+    for (int g = 0; g < 8; ++g) S += ss[g][part] * expf(sm[g][part] - M);
+    float* o = ws + (((size_t)b * ATT_SCHUNKS + chunk) * 32 + part) * 2;
+    o[0] = M;
+    o[1] = S;
+  }
+}
+
+template <int NTILES>
+__global__ __launch_bounds__(256) void att_pool_kernel(const float* __restrict__ segm, int segm_cs,
+                                                       const float* __restrict__ feat, int feat_cs, int H, int W,
+                                                       const float* __restrict__ stats, float* __restrict__ part_ws) {
+  const int b = blockIdx.x, ks = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  // global max of my part over the 16 stat chunks
+  float M = -INFINITY;
+  for (int c = 0; c < ATT_SCHUNKS; ++c) M = fmaxf(M, stats[(((size_t)b * ATT_SCHUNKS + c) * 32 + li) * 2]);
+  const int npix = H * W;
+  const int per_wave = npix / (ATT_KSPLIT * 4);
+  const int q0 = (ks * 4 + wave) * per_wave;
+  const float* sbase = segm + (size_t)b * (2 * H) * (2 * W) * segm_cs + 1 + li;
+  const float* fbase = feat + (size_t)b * npix * feat_cs + li;
+  f32x16 acc[NTILES];
+#pragma unroll
+  for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll 2
+  for (int q = q0 + lh; q < q0 + per_wave; q += 2) {
+    const int y = q / W, x = q % W;
+    const float a = expf(sbase[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs] - M);
+    const float* f = fbase + (size_t)q * feat_cs;
+    float bv[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) bv[n] = f[n * 32];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[n], acc[n], 0, 0, 0);
+  }
+  // D layout: col = lane&31 (channel within tile), row = (r&3)+8*(r>>2)+4*(lane>>5) (part)
+  float* o = part_ws + ((size_t)(b * ATT_KSPLIT + ks) * 4 + wave) * 32 * (NTILES * 32);
+#pragma unroll
+  for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      o[(size_t)p * (NTILES * 32) + n * 32 + li] = acc[n][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void att_reduce_kernel(const float* __restrict__ part_ws,
+                                                         const float* __restrict__ stats, int C,
+                                                         float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  __shared__ float inv[32];
+  if (threadIdx.x < 32) {
+    const int p = threadIdx.x;
+    float M = -INFINITY;
+    for (int c = 0; c < ATT_SCHUNKS; ++c) M = fmaxf(M, stats[(((size_t)b * ATT_SCHUNKS + c) * 32 + p) * 2]);
+    float S = 0.f;
+    for (int c = 0; c < ATT_SCHUNKS; ++c) {
+      const float* st = stats + (((size_t)b * ATT_SCHUNKS + c) * 32 + p) * 2;
+      S += st[1] * expf(st[0] - M);
+    }
+    inv[p] = 1.f / S;
+  }
+  __syncthreads();
+  const int n = 32 * C;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < ATT_KSPLIT * 4; ++k) s += part_ws[((size_t)b * ATT_KSPLIT * 4 + k) * n + i];
+    pooled[(size_t)b * n + i] = s * inv[i / C];
+  }
+}
+
+size_t attpool_ws_floats(int B, int C) {
+  return (size_t)B * ATT_SCHUNKS * 32 * 2 + (size_t)B * ATT_KSPLIT * 4 * 32 * C;
+}
+
+hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, int H, int W,
+                          float* stats_ws, float* part_ws, float* pooled, hipStream_t s) {
+  if ((H * W) % (ATT_KSPLIT * 4 * 2) != 0 || (H * W) % ATT_SCHUNKS != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(att_stats_kernel, dim3(B, ATT_SCHUNKS), dim3(256), 0, s, segm, segm_cs, H, W, stats_ws);
+  if (C == 320)
+    hipLaunchKernelGGL(att_pool_kernel<10>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
+                       stats_ws, part_ws);
+  else if (C == 64)
+    hipLaunchKernelGGL(att_pool_kernel<2>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
+                       stats_ws, part_ws);
+  else if (C == 32)
+    hipLaunchKernelGGL(att_pool_kernel<1>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
+                       stats_ws, part_ws);
+  else
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(att_reduce_kernel, dim3(B), dim3(256), 0, s, part_ws, stats_ws, C, pooled);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pare bias (acr/model.py:141-164): per frame and hand
+//   offsets[j*6+o] = sum_c LC[o][c][j] * pooled[part0+j][c]            (LocallyConnected2d, :559-569)
+//   shape[k]       = lin_b[k] + sum_{c,j} lin_w[k][c*16+j] * pooled[part0+j][256+c]
+//   bias[co]       = mix_b[co] + sum_k mix_wp[co][k] * [offsets|shape][k]     (pare is spatially constant)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void parebias_kernel(const PareArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float pl[16 * 320];
+  __shared__ float pare[112];
+  __shared__ float red[10][4];
+  for (int i = tid; i < 16 * a.C; i += 256) pl[i] = a.pooled[((size_t)b * 32 + a.part0) * a.C + i];
+  __syncthreads();
+  if (tid < 96) {
+    const int j = tid / 6, o = tid % 6;
+    float s = 0.f;
+    for (int c = 0; c < 256; ++c) s += a.lc_w[(o * 256 + c) * 16 + j] * pl[j * a.C + c];
+    pare[tid] = s;
+  }
+  float part[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) part[k] = 0.f;
+  for (int i = tid; i < 1024; i += 256) {
+    const float x = pl[(i & 15) * a.C + 256 + (i >> 4)];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) part[k] += a.lin_w[k * 1024 + i] * x;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    float v = part[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) red[k][tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid < 10) pare[96 + tid] = a.lin_b[tid] + ((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));
+  __syncthreads();
+  if (tid < 109) {
+    float s = a.mix_b[tid];
+    for (int k = 0; k < 106; ++k) s += a.mix_wp[tid * 106 + k] * pare[k];
+    a.out[(size_t)b * a.out_stride + tid] = s;
+  } else if (tid < a.out_stride) {
+    a.out[(size_t)b * a.out_stride + tid] = 0.f;
+  }
+}
+hipError_t launch_parebias(const PareArgs& a, hipStream_t s) {
+  if (a.C != 320 || a.out_stride > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(parebias_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Center decode, one workgroup per frame (acr/result_parser.py:85-190,218-249; acr/utils.py:334-382,773-906)
+// ------------------------------------------------------------------------------------------------
+__device__ inline void rot6d_to_aa(const float* x6, float* aa) {
+  // x.view(3,2): b1 = (x0,x2,x4), a2 = (x1,x3,x5)  (acr/utils.py:362-376)
+  float b1[3] = {x6[0], x6[2], x6[4]}, a2[3] = {x6[1], x6[3], x6[5]};
+  float n1 = fmaxf(sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]), 1e-6f);
+  b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
+  const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  float b2[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+  float n2 = fmaxf(sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]), 1e-6f);
+  b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+  // R = [b1 b2 b3] as columns; t = R^T, so t[i][j] = R[j][i]: rows of t are b1, b2, b3
+  const float t00 = b1[0], t01 = b1[1], t02 = b1[2];
+  const float t10 = b2[0], t11 = b2[1], t12 = b2[2];
+  const float t20 = b3[0], t21 = b3[1], t22 = b3[2];
+  float q[4], tr;
+  if (t22 < 1e-6f) {
+    if (t00 > t11) {
+      tr = 1.f + t00 - t11 - t22;
+      q[0] = t12 - t21; q[1] = tr; q[2] = t01 + t10; q[3] = t20 + t02;
+    } else {
+      tr = 1.f - t00 + t11 - t22;
+      q[0] = t20 - t02; q[1] = t01 + t10; q[2] = tr; q[3] = t12 + t21;
+    }
+  } else {
+    if (t00 < -t11) {
+      tr = 1.f - t00 - t11 + t22;
+      q[0] = t01 - t10; q[1] = t20 + t02; q[2] = t12 + t21; q[3] = tr;
+    } else {
+      tr = 1.f + t00 + t11 + t22;
+      q[0] = tr; q[1] = t12 - t21; q[2] = t20 - t02; q[3] = t01 - t10;
+    }
+  }
+  const float sc = 0.5f / sqrtf(tr);
+  // reference: q /= sqrt(t); q *= 0.5
+  const float rs = sqrtf(tr);
+  q[0] = (q[0] / rs) * 0.5f; q[1] = (q[1] / rs) * 0.5f; q[2] = (q[2] / rs) * 0.5f; q[3] = (q[3] / rs) * 0.5f;
+  (void)sc;
+  const float s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const float sn = sqrtf(s2), cs = q[0];
+  const float two_theta = 2.0f * (cs < 0.f ? atan2f(-sn, -cs) : atan2f(sn, cs));
+  const float k = s2 > 0.f ? two_theta / sn : 2.0f;
+  for (int e = 0; e < 3; ++e) {
+    float v = q[1 + e] * k;
+    aa[e] = (v != v) ? 0.f : v;   // NaN -> 0 (acr/utils.py:359)
+  }
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float cmap[2][64 * 64];
+  __shared__ float bestv[2][4];
+  __shared__ int besti[2][4];
+  __shared__ int s_flat[2], s_flag[2], s_prior;
+  __shared__ float s_score[2];
+  __shared__ float pred[2][112];
+  for (int h = 0; h < 2; ++h)
+    for (int i = tid; i < 4096; i += 256) cmap[h][i] = a.center[h][((size_t)b * 4096 + i) * a.center_cs];
+  __syncthreads();
+  for (int h = 0; h < 2; ++h) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < 4096; i += 256) {
+      const int y = i >> 6, x = i & 63;
+      const float v = cmap[h][i];
+      float m = v;
+      for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) m = fmaxf(m, cmap[h][yy * 64 + xx]);
+        }
+      const float det = (m == v) ? v : v * 0.f;      // x * (maxpool(x) == x)  (acr/result_parser.py:245-249)
+      if (det > bv || (det == bv && i < bi)) { bv = det; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_down(bv, off, 64);
+      const int oi = __shfl_down(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { bestv[h][tid >> 6] = bv; besti[h][tid >> 6] = bi; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int h = 0; h < 2; ++h) {
+      float bv = bestv[h][0];
+      int bi = besti[h][0];
+      for (int w = 1; w < 4; ++w)
+        if (bestv[h][w] > bv || (bestv[h][w] == bv && besti[h][w] < bi)) { bv = bestv[h][w]; bi = besti[h][w]; }
+      s_flag[h] = bv > 0.35f;                         // strict (acr/result_parser.py:241)
+      s_flat[h] = s_flag[h] ? bi : 0;                 // placeholder samples pixel 0 (:106-120)
+      s_score[h] = bv;
+    }
+    int use = s_flag[0] && s_flag[1];
+    if (use) {                                        // determine_coeff (:42-47): > 32 px apart -> no prior
+      const float dy = (float)(s_flat[0] >> 6) - (float)(s_flat[1] >> 6);
+      const float dx = (float)(s_flat[0] & 63) - (float)(s_flat[1] & 63);
+      if (sqrtf(dy * dy + dx * dx) > 32.f) use = 0;
+    }
+    s_prior = use;
+  }
+  __syncthreads();
+  if (tid < 218) {
+    const int h = tid / 109, c = tid % 109;
+    float v = a.params[h][((size_t)b * 4096 + s_flat[h]) * a.params_cs + c];
+    if (s_prior && c >= 3)                            // own prior map at the OTHER hand's center (:141-145)
+      v += a.prior[h][((size_t)b * 4096 + s_flat[1 - h]) * a.prior_cs + (c - 3)];
+    pred[h][c] = v;
+  }
+  __syncthreads();
+  float* slot0 = a.slots + (size_t)b * 2 * ACRMI_SLOT;
+  if (tid < 218) {
+    const int h = tid / 109, c = tid % 109;
+    float* sl = slot0 + h * ACRMI_SLOT;
+    const float v = pred[h][c];
+    sl[ACRMI_SLOT_PARAMS + c] = v;
+    if (c < 3) sl[ACRMI_SLOT_CAM + c] = v;
+    if (c >= 99) sl[ACRMI_SLOT_BETAS + (c - 99)] = v;
+    if (c == 0) {
+      sl[ACRMI_SLOT_FLAG] = (float)s_flag[h];
+      sl[ACRMI_SLOT_FLATIND] = (float)s_flat[h];
+      sl[ACRMI_SLOT_SCORE] = s_score[h];
+      sl[173] = 0.f; sl[174] = 0.f; sl[175] = 0.f;
+    }
+  }
+  if (tid >= 224 && tid < 256) {
+    const int k = tid - 224, h = k >> 4, j = k & 15;
+    float aa[3];
+    rot6d_to_aa(&pred[h][3 + 6 * j], aa);
+    float* sl = slot0 + h * ACRMI_SLOT + ACRMI_SLOT_POSES + 3 * j;
+    sl[0] = aa[0]; sl[1] = aa[1]; sl[2] = aa[2];
+  }
+}
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace acrmi

@@ -1,0 +1,92 @@
+// Internal launch interface between the C ABI (acrmi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acrmi {
+
+struct ConvArgs {
+  const float* in;
+  const float* w;      // packed [group][tap][cin8][ntile][lane64][4]
+  const float* bias;   // [group][coutP] or per frame
+  const float* res;    // may be null
+  float* out;
+  int B, H, W, Ho, Wo;
+  int in_cs, in_coff, Cin;
+  int out_cs, out_coff, Cout;
+  int res_cs, res_coff;
+  int ks, stride, relu, groups;
+  int n_tiles;          // 32-cout tiles per group in the packed weights (CoutP/32)
+  int cin8;             // ceil(Cin/8)
+  int bias_fstride;     // floats between frames' bias rows (0 = shared)
+};
+
+// returns hipSuccess or the launch error; cout tiles etc. derived inside
+hipError_t launch_conv(ConvArgs a, hipStream_t s);
+const char* conv_kernel_name(const ConvArgs& a);
+
+hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStream_t s);
+hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,
+                             int out_cs, int out_coff, hipStream_t s);
+struct FuseArgs {
+  const float* term[4];
+  int cs[4], shift[4];
+  int nterms, B, H, W, C, out_cs, relu;
+  float* out;
+};
+hipError_t launch_fuse_sum(const FuseArgs& a, hipStream_t s);
+hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s);
+hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, hipStream_t s);
+
+// attention pooling: segm [B,2H,2W,segm_cs] logits (channels 1..32 at even pixels), feat [B,H,W,feat_cs] (C ch)
+// stats_ws: [B,32,2] (max, 1/sumexp); pooled [B,32,C]
+constexpr int ATT_KSPLIT = 8;
+hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, int H, int W,
+                          float* stats_ws, float* part_ws, float* pooled, hipStream_t s);
+size_t attpool_ws_floats(int B, int C);
+
+// pare bias: pooled [B,32,320] -> per-frame bias row [B, biasP] for the 109->109 mix conv
+struct PareArgs {
+  const float* pooled;   // [B,32,C] (C = 320: 256 contact + 64 shape)
+  const float* lc_w;     // LocallyConnected2d weight [6][256][16]
+  const float* lin_w;    // [10][1024]
+  const float* lin_b;    // [10]
+  const float* mix_wp;   // [109][106] columns of the mix conv that multiply pare
+  const float* mix_b;    // [109]
+  float* out;            // [B, out_stride]
+  int B, C, part0, out_stride;
+};
+hipError_t launch_parebias(const PareArgs& a, hipStream_t s);
+
+struct DecodeArgs {
+  const float* center[2];
+  const float* params[2];
+  const float* prior[2];
+  int center_cs, params_cs, prior_cs;
+  int B;
+  float* slots;
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+
+struct ManoTables {   // device pointers
+  const float* v_template;   // [778*3]
+  const float* shapedirs_t;  // [10][2334]   (transposed for coalesced reads)
+  const float* posedirs_t;   // [135][2334]
+  const float* jreg;         // [16][778]
+  const float* weights;      // [778][16]
+  const float* hands_mean;   // [45]
+};
+struct ManoArgs {
+  ManoTables t[2];
+  const float* poses; int pose_stride;
+  const float* betas; int beta_stride;
+  const int32_t* side;
+  int H, center_idx;
+  float *verts, *joints, *center;
+  const float* cam; int cam_stride;
+  const float* offsets; int off_div;   // offsets row = hand row / off_div
+  float *verts_camed, *pj2d, *pj2d_org;
+};
+hipError_t launch_mano(const ManoArgs& a, hipStream_t s);
+
+}  // namespace acrmi

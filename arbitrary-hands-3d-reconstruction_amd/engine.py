@@ -1,0 +1,191 @@
+"""Engine: one libacrmi context on one GPU.  torch tensors are used only as HBM containers
+(allocation, stream handle, host<->device copies); all arithmetic runs in libacrmi.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, packer
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine(object):
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.AcrmiError('no GPU visible: the ACR path runs only on the HIP kernels (no CPU fallback)')
+        self.L = _lib.lib()
+        self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
+        self.ctx = C.c_void_p()
+        _lib.check(self.L.acrmi_create(C.byref(self.ctx), self.device.index))
+        self.max_batch = 0
+        self.program = None
+        self.have_mano = False
+
+    def close(self):
+        if self.ctx:
+            self.L.acrmi_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup ---------------------------------------------------------------------------------
+    def load_state_dict(self, sd, max_batch=1):
+        """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights."""
+        prog = packer.lower(sd)
+        blob = prog['blob']
+        _lib.check(self.L.acrmi_load_weights(self.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), self.ctx)
+        self.program = prog
+        self._set_program(max_batch)
+
+    def _set_program(self, max_batch):
+        prog = self.program
+        bufs = (_lib.BufferDesc * len(prog['bufs']))(*[_lib.BufferDesc(*b) for b in prog['bufs']])
+        ops = (_lib.Op * len(prog['ops']))(*prog['ops'])
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            _lib.check(self.L.acrmi_set_program(self.ctx, bufs, len(bufs), ops, len(ops), C.byref(prog['heads']),
+                                                max_batch), self.ctx)
+        self.max_batch = max_batch
+
+    def ensure_batch(self, B):
+        if self.program is None:
+            raise _lib.AcrmiError('no checkpoint loaded')
+        if B > self.max_batch:
+            self._set_program(B)
+
+    def load_mano(self, tables):
+        """tables: {'left': {...}, 'right': {...}} numpy arrays as registered by mano/manolayer.py:61-102.
+        The left-hand shapedirs x-flip (acr/mano_wrapper.py:35) must already be applied by the caller."""
+        for side, name in ((0, 'left'), (1, 'right')):
+            t = tables[name]
+            arrs = [np.ascontiguousarray(np.asarray(t[k], np.float32)) for k in
+                    ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'hands_mean')]
+            shapes = [(778, 3), (778, 3, 10), (778, 3, 135), (16, 778), (778, 16), (45,)]
+            for a, s in zip(arrs, shapes):
+                if a.shape != s and a.reshape(-1).shape != (int(np.prod(s)),):
+                    raise ValueError('MANO table has shape %s, expected %s' % (a.shape, s))
+            _lib.check(self.L.acrmi_load_mano(self.ctx, side, *[a.ctypes.data_as(C.c_void_p) for a in arrs]), self.ctx)
+        self.have_mano = True
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def _check_img(self, img):
+        if img.dtype != torch.uint8 or img.dim() != 4 or tuple(img.shape[1:]) != (512, 512, 3):
+            raise ValueError('image must be uint8 [B,512,512,3] RGB, got %s %s' % (img.dtype, tuple(img.shape)))
+        if img.device != self.device:
+            img = img.to(self.device)
+        return img.contiguous()
+
+    def backbone_heads(self, img):
+        img = self._check_img(img)
+        B = img.shape[0]
+        self.ensure_batch(B)
+        _lib.check(self.L.acrmi_backbone_heads(self.ctx, _ptr(img), B, _stream(self.device)), self.ctx)
+        return B
+
+    def buffer(self, buf_id, B, channels=None):
+        """Zero-copy torch view [B,h,w,cs] of a program buffer (NHWC)."""
+        h, w, cs = C.c_int(), C.c_int(), C.c_int()
+        p = self.L.acrmi_buffer_ptr(self.ctx, buf_id, C.byref(h), C.byref(w), C.byref(cs))
+        if not p:
+            raise ValueError('no such buffer %d' % buf_id)
+        n = B * h.value * w.value * cs.value
+        arr = _DevArray(p, n, self.device)
+        t = torch.as_tensor(arr, device=self.device).view(B, h.value, w.value, cs.value)
+        return t if channels is None else t[..., :channels]
+
+    def head_maps(self, B, nchw=True):
+        """The reference's H11 output dict (acr/model.py:56-63) from the resident head buffers."""
+        hl = self.program['heads']
+        out = {}
+        for si, side in enumerate('lr'):
+            out[side + '_params_maps'] = self.buffer(hl.params_buf[si], B, 109)
+            out[side + '_center_map'] = self.buffer(hl.center_buf[si], B, 1)
+            out[side + '_prior_maps'] = self.buffer(hl.prior_buf[si], B, 106)
+        out['segms'] = self.buffer(hl.segm_buf, B, 33)
+        if nchw:
+            out = {k: v.permute(0, 3, 1, 2).contiguous() for k, v in out.items()}
+        return out
+
+    def decode(self, B):
+        slots = torch.empty(B, 2, _lib.SLOT, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.acrmi_decode(self.ctx, B, _ptr(slots), _stream(self.device)), self.ctx)
+        return slots
+
+    def mano(self, poses, betas, side, center_idx=9, cam=None, offsets=None):
+        """poses [H,48], betas [H,10] float32 on device; side: int tensor [H] (0 left, 1 right)."""
+        H = poses.shape[0]
+        dev = self.device
+        poses = poses.to(dev, torch.float32).contiguous()
+        betas = betas.to(dev, torch.float32).contiguous()
+        verts = torch.empty(H, 778, 3, dtype=torch.float32, device=dev)
+        joints = torch.empty(H, 21, 3, dtype=torch.float32, device=dev)
+        center = torch.empty(H, 1, 3, dtype=torch.float32, device=dev)
+        extra = {}
+        if H == 0:
+            return verts, joints, center, extra
+        side = side.to(dev, torch.int32).contiguous()
+        vc = pj = org = None
+        if cam is not None:
+            cam = cam.to(dev, torch.float32).contiguous()
+            vc = torch.empty(H, 778, 3, dtype=torch.float32, device=dev)
+            pj = torch.empty(H, 21, 2, dtype=torch.float32, device=dev)
+            extra = {'verts_camed': vc, 'pj2d': pj}
+            if offsets is not None:
+                offsets = offsets.to(dev, torch.float32).contiguous()
+                org = torch.empty(H, 21, 2, dtype=torch.float32, device=dev)
+                extra['pj2d_org'] = org
+        _lib.check(self.L.acrmi_mano(self.ctx, _ptr(poses), 48, _ptr(betas), 10, _ptr(side), H,
+                                     -1 if center_idx is None else int(center_idx), _ptr(verts), _ptr(joints),
+                                     _ptr(center), _ptr(cam), 3, _ptr(offsets), _ptr(vc), _ptr(pj), _ptr(org),
+                                     _stream(dev)), self.ctx)
+        return verts, joints, center, extra
+
+    def forward(self, img, offsets=None, project=False, out=None):
+        """frames -> (slots [B,2,176], verts [B,2,778,3], joints [B,2,21,3][, verts_camed, pj2d, pj2d_org])."""
+        img = self._check_img(img)
+        B = img.shape[0]
+        self.ensure_batch(B)
+        dev = self.device
+        if out is None:
+            out = {'slots': torch.empty(B, 2, _lib.SLOT, dtype=torch.float32, device=dev),
+                   'verts': torch.empty(B, 2, 778, 3, dtype=torch.float32, device=dev),
+                   'joints': torch.empty(B, 2, 21, 3, dtype=torch.float32, device=dev)}
+            if project:
+                out['verts_camed'] = torch.empty(B, 2, 778, 3, dtype=torch.float32, device=dev)
+                out['pj2d'] = torch.empty(B, 2, 21, 2, dtype=torch.float32, device=dev)
+                if offsets is not None:
+                    out['pj2d_org'] = torch.empty(B, 2, 21, 2, dtype=torch.float32, device=dev)
+        if offsets is not None:
+            offsets = offsets.to(dev, torch.float32).contiguous()
+        _lib.check(self.L.acrmi_forward(self.ctx, _ptr(img), B, _ptr(offsets), _ptr(out['slots']), _ptr(out['verts']),
+                                        _ptr(out['joints']), _ptr(out.get('verts_camed')), _ptr(out.get('pj2d')),
+                                        _ptr(out.get('pj2d_org')), _stream(dev)), self.ctx)
+        return out
+
+    def profile_ops(self, img):
+        img = self._check_img(img)
+        B = img.shape[0]
+        self.ensure_batch(B)
+        n = len(self.program['ops'])
+        ms = (C.c_float * n)()
+        _lib.check(self.L.acrmi_profile_ops(self.ctx, _ptr(img), B, ms, n, _stream(self.device)), self.ctx)
+        return [dict(info, ms=float(ms[i])) for i, info in enumerate(self.program['op_info'])]
+
+
+class _DevArray(object):
+    """__cuda_array_interface__ shim so torch can view library-owned HBM without copying."""
+
+    def __init__(self, ptr, n, device):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+        self.device = device

@@ -1,0 +1,113 @@
+"""Stand-alone operator wrappers over the C ABI (NHWC fp32 device tensors in, device tensors out).
+Same kernels the resident program uses; handy for parity tests and for embedding single ops."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .packer import pack_conv, n_tiles_for
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.AcrmiError('device tensors required: libacrmi has no CPU path')
+
+
+def to_nhwc(x_nchw, cs=None, device='cuda'):
+    """[B,C,H,W] (any device) -> contiguous NHWC on `device` with channel stride cs (zero padded)."""
+    B, Cc, H, W = x_nchw.shape
+    cs = cs or (Cc + 3) // 4 * 4
+    out = torch.zeros(B, H, W, cs, dtype=torch.float32, device=device)
+    out[..., :Cc] = x_nchw.permute(0, 2, 3, 1).to(device)
+    return out
+
+
+def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, cin=None, in_coff=0, out=None,
+           out_coff=0, out_cs=None, frame_bias=None):
+    """x: NHWC [B,H,W,cs] device fp32; weight: [Cout_total, Cin/groups, k, k] (torch/numpy, host or device);
+    padding = k//2 (the only padding the ACR network uses).  Returns NHWC [B,Ho,Wo,out_cs]."""
+    _need_cuda(x, residual, out, frame_bias)
+    w = weight.detach().cpu().numpy() if hasattr(weight, 'detach') else np.asarray(weight)
+    cout_t, cin_g, k, _ = w.shape
+    cout = cout_t // groups
+    b = np.zeros(cout_t, np.float32) if bias is None else (
+        bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
+    packed = [pack_conv(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout]) for g in range(groups)]
+    wp = torch.from_numpy(np.concatenate([p[0] for p in packed])).to(x.device)
+    bp = torch.from_numpy(np.concatenate([p[1] for p in packed])).to(x.device)
+    B, H, W, cs = x.shape
+    cin = cin_g if cin is None else cin
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out_cs = out_cs or (cout_t + 3) // 4 * 4
+        out = torch.zeros(B, Ho, Wo, out_cs, dtype=torch.float32, device=x.device)
+    bias_t, fstride = bp, 0
+    if frame_bias is not None:
+        bias_t, fstride = frame_bias.contiguous(), frame_bias.shape[-1]
+    L = _lib.lib()
+    _lib.check(L.acrmi_conv2d(_p(x), B, H, W, cs, in_coff, cin, _p(wp), _p(bias_t), fstride, _p(residual),
+                              residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1], out_coff,
+                              cout, k, stride, int(relu), groups, _s(x)))
+    return out
+
+
+def u8norm(img):
+    _need_cuda(img)
+    B, H, W, _ = img.shape
+    out = torch.empty(B, H, W, 4, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().acrmi_u8norm(_p(img.contiguous()), B * H * W, _p(out), _s(img)))
+    return out
+
+
+def bilinear2x(x, channels=None):
+    _need_cuda(x)
+    B, H, W, cs = x.shape
+    Cc = channels or cs
+    out = torch.zeros(B, 2 * H, 2 * W, Cc, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().acrmi_bilinear2x(_p(x), B, H, W, cs, Cc, _p(out), Cc, _s(x)))
+    return out
+
+
+def fuse_sum(terms, shifts, relu=True):
+    _need_cuda(*terms)
+    B, H, W, Cc = terms[0].shape
+    n = len(terms)
+    out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=terms[0].device)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in terms])
+    cs = (C.c_int * n)(*[t.shape[-1] for t in terms])
+    sh = (C.c_int * n)(*shifts)
+    _lib.check(_lib.lib().acrmi_fuse_sum(n, ptrs, cs, sh, B, H, W, Cc, _p(out), Cc, int(relu), _s(out)))
+    return out
+
+
+def attpool(segm, feat, channels):
+    """segm NHWC [B,256,256,cs] logits, feat NHWC [B,128,128,cs]; -> pooled [B,32,channels]."""
+    _need_cuda(segm, feat)
+    B = segm.shape[0]
+    ws = torch.empty(B * 16 * 32 * 2 + B * 32 * 32 * channels, dtype=torch.float32, device=segm.device)
+    pooled = torch.empty(B, 32, channels, dtype=torch.float32, device=segm.device)
+    _lib.check(_lib.lib().acrmi_attpool(_p(segm), segm.shape[-1], _p(feat), feat.shape[-1], channels, B, _p(ws),
+                                        _p(pooled), _s(segm)))
+    return pooled
+
+
+def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior):
+    """NHWC device maps -> slots [B,2,176]."""
+    _need_cuda(l_center, r_center, l_params, r_params, l_prior, r_prior)
+    B = l_center.shape[0]
+    slots = torch.empty(B, 2, _lib.SLOT, dtype=torch.float32, device=l_center.device)
+    _lib.check(_lib.lib().acrmi_decode_maps(_p(l_center), _p(r_center), l_center.shape[-1], _p(l_params), _p(r_params),
+                                            l_params.shape[-1], _p(l_prior), _p(r_prior), l_prior.shape[-1], B,
+                                            _p(slots), _s(slots)))
+    return slots

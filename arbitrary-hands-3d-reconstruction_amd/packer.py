@@ -1,0 +1,340 @@
+"""Checkpoint -> (packed weight blob, op program) for libacrmi.so.
+
+Takes a reference-format state dict (schema.py; keys of acr.model.ACR().state_dict(),
+optionally prefixed 'module.' as in wild.pkl, acr/utils.py:1106-1113), folds every
+eval-mode BatchNorm into its convolution (w' = w*g/sqrt(var+eps), b' = beta + (b-mean)*g/sqrt(var+eps),
+eps = 1e-5), packs the weights in the MFMA B-fragment order conv_mfma.hip reads, and lowers the
+HRNet-W32 + ACR-head topology (acr/model.py:785-865, :47-166) to a flat list of ops over NHWC
+activation buffers.  Pure numpy; runs on the host once per checkpoint.
+"""
+import numpy as np
+
+from . import _lib
+from .schema import STAGE_CFG, state_dict_schema
+
+EPS = 1e-5
+
+
+def _np(t):
+    if hasattr(t, 'detach'):
+        t = t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def strip_prefix(sd, prefix='module.'):
+    """acr/utils.py:1106-1151 (copy_state_dict): accept both bare and 'module.'-prefixed keys,
+    unwrap 'model_state_dict' / 'state_dict' containers (:1159-1163)."""
+    for k in ('model_state_dict', 'state_dict'):
+        if k in sd and isinstance(sd[k], dict):
+            sd = sd[k]
+    out = {}
+    for k, v in sd.items():
+        out[k[len(prefix):] if k.startswith(prefix) else k] = v
+    return out
+
+
+def check_state_dict(sd):
+    want = state_dict_schema()
+    missing = [k for k in want if k not in sd and not k.startswith('segmentation_layers.')
+               and not k.endswith('num_batches_tracked')]
+    if missing:
+        raise ValueError('checkpoint is missing %d tensors, e.g. %s' % (len(missing), missing[:3]))
+    for k, shp in want.items():
+        if k in sd and tuple(_np(sd[k]).shape) != tuple(shp):
+            raise ValueError('checkpoint tensor %s has shape %s, expected %s' % (k, tuple(_np(sd[k]).shape), shp))
+
+
+def n_tiles_for(cout):
+    return 1 if cout <= 32 else ((cout + 63) // 64) * 2
+
+
+def pack_conv(w, b):
+    """w [Cout,Cin,k,k], b [Cout] (float64/32) -> (packed weights fp32 1-D, padded bias fp32 [n_tiles*32]).
+    Packed index: [tap][s = ci/8][ntile][lane 64][e 4] with cout = ntile*32 + (lane & 31),
+    ci = 8*s + 4*(lane >> 5) + e."""
+    cout, cin, k, _ = w.shape
+    nt = n_tiles_for(cout)
+    c8 = (cin + 7) // 8
+    wp = np.zeros((nt * 32, c8 * 8, k, k), np.float32)
+    wp[:cout, :cin] = w
+    wp = wp.reshape(nt, 32, c8, 2, 4, k, k)             # [nt, j, s, h, e, ky, kx]
+    wp = wp.transpose(5, 6, 2, 0, 3, 1, 4)               # [ky, kx, s, nt, h, j, e]
+    bp = np.zeros(nt * 32, np.float32)
+    bp[:cout] = b
+    return np.ascontiguousarray(wp).reshape(-1), bp
+
+
+class Blob(object):
+    def __init__(self):
+        self.parts = [np.zeros(64, np.float32)]   # offset 0 reserved
+        self.n = 64
+
+    def add(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32).reshape(-1)
+        pad = (-arr.size) % 64                     # keep every tensor 256-byte aligned
+        off = self.n
+        self.parts.append(arr)
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+        self.n += arr.size + pad
+        return off
+
+    def finish(self):
+        return np.concatenate(self.parts)
+
+
+class Program(object):
+    """Op list + buffer table under construction."""
+
+    def __init__(self, sd):
+        self.sd = {k: _np(v) for k, v in sd.items()}
+        self.blob = Blob()
+        self.bufs = []           # (h, w, cs, persistent)
+        self.free = {}           # (h, w, cs) -> [ids]
+        self.ops = []
+        self.op_info = []        # python-side description (name, flops) per op
+
+    # ---- buffers -----------------------------------------------------------------------------
+    def buf(self, h, w, c, persistent=False):
+        cs = (c + 3) // 4 * 4
+        key = (h, w, cs)
+        if not persistent and self.free.get(key):
+            return self.free[key].pop()
+        self.bufs.append((h, w, cs, 1 if persistent else 0))
+        return len(self.bufs) - 1
+
+    def release(self, *ids):
+        for i in ids:
+            h, w, cs, p = self.bufs[i]
+            if not p:
+                assert i not in self.free.setdefault((h, w, cs), []), 'double release of buffer %d' % i
+                self.free[(h, w, cs)].append(i)
+
+    def dims(self, i):
+        return self.bufs[i][:3]
+
+    # ---- weights -----------------------------------------------------------------------------
+    def folded(self, conv, bn=None):
+        w = self.sd[conv + '.weight'].astype(np.float64)
+        b = self.sd.get(conv + '.bias')
+        b = np.zeros(w.shape[0]) if b is None else b.astype(np.float64)
+        if bn is not None:
+            g = self.sd[bn + '.weight'].astype(np.float64)
+            scale = g / np.sqrt(self.sd[bn + '.running_var'].astype(np.float64) + EPS)
+            w = w * scale[:, None, None, None]
+            b = self.sd[bn + '.bias'].astype(np.float64) + (b - self.sd[bn + '.running_mean'].astype(np.float64)) * scale
+        return w, b
+
+    # ---- ops ---------------------------------------------------------------------------------
+    def _op(self, name, flops=0.0, **kw):
+        op = _lib.Op()
+        for f in ('in_buf', 'out_buf', 'res_buf', 'aux_buf'):
+            setattr(op, f, -1)
+        for k, v in kw.items():
+            setattr(op, k, v)
+        self.ops.append(op)
+        self.op_info.append({'name': name, 'flops': float(flops), 'kind': int(op.kind)})
+        return op
+
+    def conv(self, name, src, wb_list, k, stride, relu, out=None, out_c=None, in_coff=0, out_coff=0, res=None,
+             res_coff=0, cin=None, bias_buf=None):
+        """wb_list: [(w, b)] one entry per group (all same shape)."""
+        h, w_, _ = self.dims(src)
+        cout, cin_w = wb_list[0][0].shape[:2]
+        cin = cin_w if cin is None else cin
+        ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w_ + 2 * (k // 2) - k) // stride + 1
+        if out is None:
+            out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
+        packed = [pack_conv(w, b) for (w, b) in wb_list]
+        w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
+        b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
+        flops = 2.0 * ho * wo * cout * cin_w * k * k * len(wb_list)
+        self._op(name, flops, kind=_lib.OP_CONV, in_buf=src, out_buf=out, res_buf=-1 if res is None else res,
+                 in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
+                 relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off,
+                 bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
+        return out
+
+    def conv_bn(self, src, conv, bn, k, stride, relu, **kw):
+        return self.conv(conv, src, [self.folded(conv, bn)], k, stride, relu, **kw)
+
+    def fuse_sum(self, name, terms, c, relu, out=None, out_coff=0):
+        """terms: [(buf, shift)]"""
+        h, w_, _ = self.dims(terms[0][0])
+        assert terms[0][1] == 0
+        if out is None:
+            out = self.buf(h, w_, c)
+        op = self._op(name, 0.0, kind=_lib.OP_FUSESUM, out_buf=out, out_coff=out_coff, cout=c, relu=int(relu),
+                      nterms=len(terms))
+        for t, (b, sh) in enumerate(terms):
+            op.term_buf[t], op.term_coff[t], op.term_shift[t] = b, 0, sh
+        return out
+
+    # ---- blocks ------------------------------------------------------------------------------
+    def basic_block(self, x, p):
+        """acr/model.py:483-499; consumes x (released), returns the new buffer."""
+        t = self.conv_bn(x, p + '.conv1', p + '.bn1', 3, 1, True)
+        y = self.conv_bn(t, p + '.conv2', p + '.bn2', 3, 1, True, res=x)
+        self.release(t, x)
+        return y
+
+    def bottleneck(self, x, p):
+        """acr/model.py:519-539"""
+        t1 = self.conv_bn(x, p + '.conv1', p + '.bn1', 1, 1, True)
+        t2 = self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, 1, True)
+        self.release(t1)
+        if (p + '.downsample.0.weight') in self.sd:
+            res = self.conv_bn(x, p + '.downsample.0', p + '.downsample.1', 1, 1, False)
+            self.release(x)
+        else:
+            res = x
+        y = self.conv_bn(t2, p + '.conv3', p + '.bn3', 1, 1, True, res=res)
+        self.release(t2, res)
+        return y
+
+    def hr_module(self, xs, p, ch, multi_scale=True, final_out=None):
+        """acr/model.py:668-686.  xs consumed; returns the fused outputs."""
+        nb = len(xs)
+        xs = list(xs)
+        for i in range(nb):
+            for k in range(4):
+                xs[i] = self.basic_block(xs[i], '%s.branches.%d.%d' % (p, i, k))
+        outs = []
+        temps = []
+        for i in range(nb if multi_scale else 1):
+            terms = []
+            for j in range(nb):
+                f = '%s.fuse_layers.%d.%d' % (p, i, j)
+                if j == i:
+                    terms.append((xs[j], 0))
+                elif j > i:
+                    t = self.conv_bn(xs[j], f + '.0', f + '.1', 1, 1, False)
+                    terms.append((t, j - i))
+                    temps.append(t)
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        t2 = self.conv_bn(t, '%s.%d.0' % (f, k), '%s.%d.1' % (f, k), 3, 2, k != i - j - 1)
+                        if t is not xs[j]:
+                            self.release(t)
+                        t = t2
+                    terms.append((t, 0))
+                    temps.append(t)
+            # fuse_sum wants the full-resolution term first for geometry; keep the reference's sum order
+            # (j ascending) by letting the kernel take per-term shifts.
+            if terms[0][1] != 0:
+                raise AssertionError('term 0 must be at output resolution')
+            if final_out is not None:
+                outs.append(self.fuse_sum(p + '.fuse%d' % i, terms, ch[i], True, out=final_out))
+            else:
+                outs.append(self.fuse_sum(p + '.fuse%d' % i, terms, ch[i], True))
+        self.release(*temps)
+        self.release(*xs)
+        return outs
+
+
+def lower(sd, check=True):
+    """state dict -> dict(blob, bufs, ops, heads, op_info).  See module docstring."""
+    sd = strip_prefix(sd)
+    if check:
+        check_state_dict(sd)
+    P = Program(sd)
+    b = 'backbone.'
+    # ---- stem -----------------------------------------------------------------------------------
+    x0 = P.buf(512, 512, 4)
+    P._op('u8norm', 0.0, kind=_lib.OP_U8NORM, out_buf=x0)
+    w, bb = P.folded(b + 'conv1', b + 'bn1')
+    x = P.conv(b + 'conv1', x0, [(w, bb)], 3, 2, True, cin=3)
+    P.op_info[-1]['flops'] = 2.0 * 256 * 256 * 64 * 3 * 9
+    P.release(x0)
+    x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True)
+    P.release(x)
+    x = x1
+    for i in range(4):
+        x = P.bottleneck(x, b + 'layer1.%d' % i)
+    # ---- stages ---------------------------------------------------------------------------------
+    t = b + 'transition1'
+    xs = [P.conv_bn(x, t + '.0.0', t + '.0.1', 3, 1, True), P.conv_bn(x, t + '.1.0.0', t + '.1.0.1', 3, 2, True)]
+    P.release(x)
+    x34 = P.buf(128, 128, 34, persistent=True)      # backbone output (32) + coord maps (2), acr/model.py:52
+    P._op('coordfill', 0.0, kind=_lib.OP_COORDFILL, out_buf=x34, out_coff=32)
+    for s in (2, 3, 4):
+        ch = STAGE_CFG[s]['channels']
+        if s > 2:
+            t = b + 'transition%d' % (s - 1)
+            i = len(ch) - 1
+            xs = xs + [P.conv_bn(xs[-1], t + '.%d.0.0' % i, t + '.%d.0.1' % i, 3, 2, True)]
+        nmod = STAGE_CFG[s]['modules']
+        for m in range(nmod):
+            last = (s == 4 and m == nmod - 1)
+            xs = P.hr_module(xs, b + 'stage%d.%d' % (s, m), ch, multi_scale=not last,
+                             final_out=x34 if last else None)
+    # ---- part-segmentation head (acr/model.py:374-463) ------------------------------------------
+    u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
+    g = b + 'hand_segm.segm_head.segm_net.double_conv'
+    up = P.buf(256, 256, 32)
+    P._op('segm.bilinear2x', 0.0, kind=_lib.OP_BILINEAR2X, in_buf=x34, out_buf=up, cin=32)
+    s1 = P.conv_bn(up, u + '.0', u + '.1', 3, 1, True)
+    P.release(up)
+    s2 = P.conv_bn(s1, u + '.3', u + '.4', 3, 1, True)
+    P.release(s1)
+    s3 = P.conv_bn(s2, g + '.0', g + '.1', 3, 1, True)
+    P.release(s2)
+    segm = P.buf(256, 256, 33, persistent=True)
+    P.conv(g + '.3', s3, [P.folded(g + '.3')], 3, 1, False, out=segm)
+    P.release(s3)
+    # ---- 8 head towers (acr/model.py:71-92, 288-313), batched as one 34->512 conv + grouped blocks --
+    towers = [(side, k) for side in 'lr' for k in (1, 2, 3, 4)]
+    w_list = [P.folded('%s_final_layers.%d.0.0' % t, '%s_final_layers.%d.0.1' % t) for t in towers]
+    wcat = np.concatenate([w for w, _ in w_list], 0)
+    bcat = np.concatenate([bb for _, bb in w_list], 0)
+    t0 = P.conv('towers.entry', x34, [(wcat, bcat)], 3, 2, True, cin=34)
+    for k in range(2):
+        c1 = [P.folded('%s_final_layers.%d.1.%d.0.conv1' % (s_, t_, k), '%s_final_layers.%d.1.%d.0.bn1' % (s_, t_, k))
+              for s_, t_ in towers]
+        c2 = [P.folded('%s_final_layers.%d.1.%d.0.conv2' % (s_, t_, k), '%s_final_layers.%d.1.%d.0.bn2' % (s_, t_, k))
+              for s_, t_ in towers]
+        t1 = P.conv('towers.block%d.conv1' % k, t0, c1, 3, 1, True)
+        t2 = P.conv('towers.block%d.conv2' % k, t1, c2, 3, 1, True, res=t0)
+        P.release(t1, t0)
+        t0 = t2
+    heads = _lib.HeadLayout()
+    p109 = {}
+    for si, side in enumerate('lr'):
+        p109[side] = P.buf(64, 64, 109)
+        center = P.buf(64, 64, 1, persistent=True)
+        prior = P.buf(64, 64, 106, persistent=True)
+        for k, (dst, coff) in ((1, (p109[side], 3)), (2, (center, 0)), (3, (p109[side], 0)), (4, (prior, 0))):
+            ti = towers.index((side, k))
+            name = '%s_final_layers.%d.2' % (side, k)
+            P.conv(name, t0, [P.folded(name)], 1, 1, False, out=dst, in_coff=64 * ti, out_coff=coff, cin=64)
+        P._op('%s.cam_pow' % side, 0.0, kind=_lib.OP_POW11, out_buf=p109[side], out_coff=0)
+        heads.center_buf[si], heads.prior_buf[si] = center, prior
+    P.release(t0)
+    # ---- part branch (acr/model.py:116-166) ---------------------------------------------------------
+    feat = P.buf(128, 128, 320)
+    P.conv('contact_layers.1.0', x34, [P.folded('contact_layers.1.0', 'contact_layers.1.1')], 3, 1, True, out=feat, cin=34)
+    P.conv('cam_shape_layers.1.0', feat, [P.folded('cam_shape_layers.1.0')], 1, 1, False, out=feat, out_coff=256, cin=256)
+    pooled = P.buf(1, 32, 320)
+    P._op('attpool', 2.0 * 32 * 16384 * 320, kind=_lib.OP_ATTPOOL, in_buf=segm, res_buf=feat, out_buf=pooled, cin=320)
+    P.release(feat)
+    for si, (side, lc, mix, part0) in enumerate((('l', 2, 4, 16), ('r', 3, 5, 0))):
+        wm = sd['contact_layers.%d.weight' % mix]
+        wm = _np(wm).astype(np.float64).reshape(109, 218)
+        wa = wm[:, :109].copy()
+        wa[:, :3] += wm[:, 109:112]                 # cam3 appears twice in the concat (acr/model.py:160-163)
+        wp = wm[:, 112:]
+        bias_buf = P.buf(1, 1, 112)
+        P._op('%s.parebias' % side, 0.0, kind=_lib.OP_PAREBIAS, in_buf=pooled, out_buf=bias_buf, cin=320, flags=part0,
+              w_off=P.blob.add(_np(sd['contact_layers.%d.weight' % lc]).reshape(6, 256, 16)),
+              w_off2=P.blob.add(_np(sd['cam_shape_layers.%d.weight' % lc])),
+              b_off2=P.blob.add(_np(sd['cam_shape_layers.%d.bias' % lc])),
+              w_off3=P.blob.add(wp), b_off=P.blob.add(_np(sd['contact_layers.%d.bias' % mix])))
+        final = P.buf(64, 64, 109, persistent=True)
+        P.conv('contact_layers.%d' % mix, p109[side], [(wa.reshape(109, 109, 1, 1), np.zeros(109))], 1, 1, False,
+               out=final, cin=109, bias_buf=bias_buf)
+        P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 109 * 218
+        heads.params_buf[si] = final
+        P.release(bias_buf)
+    heads.segm_buf, heads.backbone_buf = segm, x34
+    return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info}

@@ -62,7 +62,8 @@ def make_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefix=''):
             out[prefix + '%s_final_layers.%d.2.weight' % (side, t)] *= 0.3
     if as_torch:
         import torch
-        out = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
+        out = {k: (torch.tensor(int(v)) if v.ndim == 0 else torch.from_numpy(np.ascontiguousarray(v)))
+               for k, v in out.items()}
     return out
 
 

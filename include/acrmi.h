@@ -1,0 +1,176 @@
+/*
+ * acrmi.h - C ABI of libacrmi.so: the MI355X (gfx950) ACR inference hot path.
+ *
+ * uint8 frame batch -> HRNet-W32 backbone -> ACR heads -> center decode -> MANO (L+R)
+ * -> 778x3 vertices + 21x3 joints per hand.  Plain pointers and sizes only: no torch,
+ * no C++ types.  All pointers marked "dev" are device (HBM) pointers owned by the caller
+ * unless stated otherwise; every call is asynchronous on the given hipStream_t (passed as
+ * void*; NULL = the null stream) and performs no hidden synchronisation.  Return value:
+ * 0 on success, a negative ACRMI_E* code otherwise (acrmi_last_error() has the text).
+ * One context per device, not thread-safe (the reference is single-threaded:
+ * /root/reference/acr/main.py:126-141).
+ *
+ * The reference has no FFI layer; each entry point names the reference Python
+ * interface it replaces (paths relative to the reference tree).
+ */
+#ifndef ACRMI_H
+#define ACRMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACRMI_VERSION 100
+
+#define ACRMI_OK 0
+#define ACRMI_EINVAL (-1)  /* bad argument / unsupported shape  (reference: ValueError / assert) */
+#define ACRMI_EHIP (-2)    /* HIP runtime error                                              */
+#define ACRMI_ESTATE (-3)  /* call order violated (weights/program/MANO tables not loaded)   */
+#define ACRMI_ENOMEM (-4)
+
+typedef struct acrmi_ctx acrmi_ctx;
+
+/* ---------------------------------------------------------------------------------------
+ * Program description.  The Python host (packer.py) folds BatchNorm into the conv weights,
+ * packs them in the MFMA fragment order, and lowers the network topology
+ * (acr/model.py:785-865 backbone, :47-166 heads) into a flat op list over numbered
+ * activation buffers (NHWC fp32, channel stride = cs floats).  The library owns the
+ * buffers and replays the list; it knows nothing about HRNet.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t h, w, cs;      /* per-frame height, width, channel stride (floats, multiple of 4) */
+  int32_t persistent;    /* 1: never aliased with another buffer (holds init-time constants) */
+} acrmi_buffer_desc;
+
+enum {
+  ACRMI_OP_U8NORM = 1,   /* uint8 NHWC image -> fp32 (x/255*2-1), pad channel zeroed (acr/model.py:832) */
+  ACRMI_OP_CONV = 2,     /* KxK conv (K in {1,3}, stride in {1,2}) + bias [+ residual] [+ ReLU] */
+  ACRMI_OP_FUSESUM = 3,  /* out = [relu](sum_t nearest_up(term_t, 2^shift_t))  (acr/model.py:677-684) */
+  ACRMI_OP_BILINEAR2X = 4, /* bilinear x2, align_corners=True (acr/model.py:432)              */
+  ACRMI_OP_POW11 = 5,    /* ch0 := 1.1 ** ch0 (acr/model.py:95-96)                            */
+  ACRMI_OP_ATTPOOL = 6,  /* softmax-over-pixels weighted feature pooling (acr/model.py:103-113) */
+  ACRMI_OP_PAREBIAS = 7, /* LocallyConnected2d + Linear + mix-conv pare bias (acr/model.py:145-164) */
+  ACRMI_OP_COORDFILL = 8 /* init-time: write coord maps into 2 channels (acr/model.py:340-369) */
+};
+
+typedef struct {
+  int32_t kind;
+  int32_t in_buf, out_buf, res_buf;       /* buffer ids, -1 = none (U8NORM: in = the image)  */
+  int32_t in_coff, out_coff, res_coff;    /* channel offsets inside the buffers              */
+  int32_t cin, cout;                      /* logical channels (per group)                    */
+  int32_t ksize, stride, relu, groups;
+  int64_t w_off, b_off;                   /* float offsets into the weight blob              */
+  int32_t bias_per_frame;                 /* 1: bias comes from aux buffer, row per frame    */
+  int32_t aux_buf;                        /* PAREBIAS/ATTPOOL output or per-frame bias input */
+  int32_t nterms;                         /* FUSESUM */
+  int32_t term_buf[4], term_coff[4], term_shift[4];
+  int64_t w_off2, b_off2, w_off3;         /* PAREBIAS: linear weights/bias, mix-conv pare columns */
+  int32_t flags;                          /* PAREBIAS: part slice start (0 right / 16 left)  */
+  int32_t reserved;
+} acrmi_op;
+
+/* Where the head outputs live (buffer ids of the program), needed by acrmi_decode. */
+typedef struct {
+  int32_t center_buf[2];   /* [left,right] center maps  [B,64,64,cs], channel 0   */
+  int32_t params_buf[2];   /* final 109-ch params maps  (acr/model.py:163-164)    */
+  int32_t prior_buf[2];    /* 106-ch prior maps                                   */
+  int32_t segm_buf;        /* 33-ch part-segmentation logits [B,256,256,cs]       */
+  int32_t backbone_buf;    /* 32(+2 coord)-ch backbone output [B,128,128,cs]      */
+} acrmi_head_layout;
+
+/* Fixed per-(frame,hand) result slot written by acrmi_decode: ACRMI_SLOT floats.
+ * hand 0 = left, 1 = right (acr/result_parser.py:166-168 ordering is rebuilt on the host). */
+#define ACRMI_SLOT 176
+#define ACRMI_SLOT_FLAG 0      /* 1.0 if center score > 0.35 (strict)                      */
+#define ACRMI_SLOT_FLATIND 1   /* y*64+x of the center (0 when not detected)               */
+#define ACRMI_SLOT_SCORE 2
+#define ACRMI_SLOT_CAM 3       /* 3  */
+#define ACRMI_SLOT_POSES 6     /* 48: global orient (3) + 15 joints axis-angle              */
+#define ACRMI_SLOT_BETAS 54    /* 10 */
+#define ACRMI_SLOT_PARAMS 64   /* 109: sampled params (+ cross-hand prior)                  */
+
+int acrmi_version(void);
+const char* acrmi_last_error(const acrmi_ctx* ctx); /* ctx may be NULL: last error of acrmi_create */
+
+/* acr/main.py:57-63 (_build_model_): one context per device. */
+int acrmi_create(acrmi_ctx** out, int device);
+void acrmi_destroy(acrmi_ctx* ctx);
+
+/* acr/utils.py:1153-1168 (load_model/copy_state_dict): host blob of packed fp32 weights
+ * (BN folded, MFMA fragment order) copied once into HBM; static residency replaces
+ * nn.DataParallel's per-call replicate (acr/main.py:61). */
+int acrmi_load_weights(acrmi_ctx* ctx, const float* blob_host, size_t n_floats);
+
+/* Lowered topology of acr/model.py:785-865 + :47-166; allocates activation buffers for
+ * up to max_batch frames (aliasing non-overlapping lifetimes) and runs the init-time ops. */
+int acrmi_set_program(acrmi_ctx* ctx, const acrmi_buffer_desc* bufs, int n_bufs, const acrmi_op* ops,
+                      int n_ops, const acrmi_head_layout* heads, int max_batch);
+
+/* mano/manolayer.py:13-102 (ManoLayer.__init__ buffers) for side 0 = left, 1 = right.
+ * Host pointers, row-major as the reference registers them: v_template[778*3],
+ * shapedirs[778*3*10], posedirs[778*3*135], J_regressor[16*778], weights[778*16],
+ * hands_mean[45].  The left-hand shapedirs x-flip (acr/mano_wrapper.py:35) is the caller's job. */
+int acrmi_load_mano(acrmi_ctx* ctx, int side, const float* v_template, const float* shapedirs,
+                    const float* posedirs, const float* J_regressor, const float* weights,
+                    const float* hands_mean);
+
+/* acr/model.py:32-44 minus the parser: backbone + head_forward on B frames.
+ * img_dev: uint8 [B,512,512,3] RGB NHWC (meta_data['image']).  Results stay in the
+ * program's head buffers (see acrmi_buffer_ptr). */
+int acrmi_backbone_heads(acrmi_ctx* ctx, const uint8_t* img_dev, int B, void* stream);
+
+/* Device pointer / geometry of program buffer `buf` (valid until the next set_program). */
+void* acrmi_buffer_ptr(acrmi_ctx* ctx, int buf, int* h, int* w, int* cs);
+
+/* acr/result_parser.py:21-40,85-190 (ResultParser.parse/parse_maps) + acr/utils.py:334-382
+ * (6D -> axis-angle), per-frame semantics: slots_dev [B,2,ACRMI_SLOT]. */
+int acrmi_decode(acrmi_ctx* ctx, int B, float* slots_dev, void* stream);
+
+/* Same decode on caller-supplied NHWC maps (unit tests / callers with their own maps):
+ * center [B,64,64,center_cs] (ch 0), params [B,64,64,params_cs] (109 ch), prior (106 ch). */
+int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs,
+                      const float* l_params, const float* r_params, int params_cs,
+                      const float* l_prior, const float* r_prior, int prior_cs, int B,
+                      float* slots_dev, void* stream);
+
+/* mano/manolayer.py:104-276 (ManoLayer.forward, use_pca=False, flat_hand_mean=False,
+ * center_idx as given; <0 = no root alignment) fused with acr/utils.py:384-412
+ * (batch_orth_proj / convert_kp2d_from_input_to_orgimg).
+ * Row r reads poses[r*pose_stride..+48], betas[r*beta_stride..+10]; side[r] (0 left / 1 right)
+ * or, when side == NULL, side = r & 1 (slot order).  cam/offsets/verts_camed/pj2d/pj2d_org may
+ * be NULL (projection skipped).  cam row stride = cam_stride, offsets [H,10] row per hand. */
+int acrmi_mano(acrmi_ctx* ctx, const float* poses, int pose_stride, const float* betas, int beta_stride,
+               const int32_t* side, int H, int center_idx, float* verts, float* joints, float* center,
+               const float* cam, int cam_stride, const float* offsets, float* verts_camed, float* pj2d,
+               float* pj2d_org, void* stream);
+
+/* acr/main.py:126-141 + :85 in one call: frames -> slots [B,2,ACRMI_SLOT], verts [B,2,778,3],
+ * joints [B,2,21,3] (root-aligned on joint 9, metres).  offsets_dev [B,10] may be NULL. */
+int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* offsets_dev, float* slots_dev,
+                  float* verts_dev, float* joints_dev, float* verts_camed_dev, float* pj2d_dev,
+                  float* pj2d_org_dev, void* stream);
+
+/* Stand-alone operators (same kernels the program uses; for parity tests and embedding).
+ * w_packed/bias come from the Python packer (pack_conv). */
+int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
+                 const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
+                 float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,
+                 void* stream);
+int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
+int acrmi_bilinear2x(const float* in, int B, int H, int W, int in_cs, int C, float* out, int out_cs, void* stream);
+int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, const int* term_shift, int B, int H,
+                   int W, int C, float* out, int out_cs, int relu, void* stream);
+int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* stats_ws,
+                  float* pooled, void* stream);
+
+/* Profiling aid for bench.py: time every op of the program with hipEvents on `stream`
+ * (one untimed warm-up pass first).  ms_out[n_ops]; returns n_ops or <0. */
+int acrmi_profile_ops(acrmi_ctx* ctx, const uint8_t* img_dev, int B, float* ms_out, int n_ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACRMI_H */

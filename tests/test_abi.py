@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/acrmi.h declares; the ctypes structs match the C layout; the product path refuses to run
+without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, pkg
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'acrmi.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(acrmi_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = pkg('_lib')
+    lib = L.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), 'libacrmi.so does not export %s' % name
+    assert sorted(L.EXPORTS) == declared
+    assert lib.acrmi_version() == 100
+
+
+def test_struct_layout_matches_header():
+    L = pkg('_lib')
+    assert ctypes.sizeof(L.Op) == 168 and L.Op.w_off.offset == 56 and L.Op.w_off2.offset == 136
+    assert ctypes.sizeof(L.BufferDesc) == 16 and ctypes.sizeof(L.HeadLayout) == 32
+    src = open(os.path.join(ROOT, 'include', 'acrmi.h')).read()
+    for name, val in (('ACRMI_SLOT', L.SLOT), ('ACRMI_SLOT_POSES', L.SLOT_POSES), ('ACRMI_SLOT_BETAS', L.SLOT_BETAS),
+                      ('ACRMI_SLOT_PARAMS', L.SLOT_PARAMS), ('ACRMI_SLOT_CAM', L.SLOT_CAM)):
+        assert re.search(r'#define %s (\d+)' % name, src).group(1) == str(val)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_no_cpu_fallback():
+    L = pkg('_lib')
+    with pytest.raises(L.AcrmiError):
+        pkg('engine').Engine(0)
+    with pytest.raises(L.AcrmiError):
+        pkg('ops').conv2d(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 1, 1))
+    ctx = ctypes.c_void_p()
+    assert L.lib().acrmi_create(ctypes.byref(ctx), 0) == L.E_HIP       # loud failure, not a silent CPU path
+    assert b'HIP' in L.lib().acrmi_last_error(None)
+
+
+def test_null_arguments_are_rejected_without_a_gpu():
+    L = pkg('_lib')
+    lib = L.lib()
+    assert lib.acrmi_create(None, 0) == L.E_INVAL
+    assert lib.acrmi_load_weights(None, None, 0) == L.E_INVAL
+    assert lib.acrmi_decode(None, 1, None, None) == L.E_INVAL
+    assert lib.acrmi_conv2d(None, 1, 8, 8, 8, 0, 8, None, None, 0, None, 0, 0, None, 8, 0, 8, 3, 1, 0, 1, None) == L.E_INVAL

@@ -1,0 +1,110 @@
+"""GPU parity of the whole path: uint8 frames -> HRNet-W32 -> heads -> decode -> MANO, HIP vs oracle
+and vs the golden vectors captured from the reference.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import golden, pkg
+from oracle import acr_net, decode as odec, mano as omano
+
+pytestmark = pytest.mark.gpu
+
+
+def _flip_left(tables):
+    t = {k: dict(v) for k, v in tables.items()}
+    t['left']['shapedirs'] = t['left']['shapedirs'].copy()
+    t['left']['shapedirs'][:, 0, :] *= -1
+    return t
+
+
+@pytest.fixture(scope='module')
+def engine(synth_sd, mano_tables):
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=2)
+    eng.load_mano(_flip_left(mano_tables))
+    return eng
+
+
+@pytest.fixture(scope='module')
+def hip_maps(engine, frames2):
+    B = engine.backbone_heads(torch.from_numpy(frames2).cuda())
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in engine.head_maps(B).items()}
+
+
+@pytest.fixture(scope='module')
+def oracle_maps(synth_sd, frames2):
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        return acr_net.network(synth_sd, torch.from_numpy(frames2))
+
+
+def test_head_maps_match_oracle(hip_maps, oracle_maps):
+    for k in ('l_center_map', 'r_center_map', 'l_params_maps', 'r_params_maps', 'l_prior_maps', 'r_prior_maps', 'segms'):
+        a, b = hip_maps[k], oracle_maps[k]
+        assert a.shape == b.shape, k
+        err = (a - b).abs().max().item()
+        scale = b.abs().max().item()
+        assert err < 1e-4 * max(1.0, scale), (k, err, scale)      # fp32 re-association over ~60 conv layers
+
+
+def test_head_maps_match_reference_golden(hip_maps):
+    g = golden('net_frame0.npz')
+    for k in ('l_center_map', 'r_center_map'):
+        np.testing.assert_allclose(hip_maps[k][:1].numpy(), g[k], rtol=1e-4, atol=1e-4)
+    for k in ('l_params_maps', 'r_params_maps', 'l_prior_maps', 'r_prior_maps', 'segms'):
+        s, cs = cases.sub(hip_maps[k][:1].numpy(), 8192)
+        np.testing.assert_allclose(s, g[k], rtol=1e-4, atol=2e-4)
+
+
+def test_backbone_matches_reference_golden(engine, hip_maps):
+    g = golden('net_frame0.npz')
+    x = engine.buffer(engine.program['heads'].backbone_buf, 2, 34).cpu()
+    bb = x[:1, :, :, :32].permute(0, 3, 1, 2).contiguous().numpy()
+    s, cs = cases.sub(bb)
+    np.testing.assert_allclose(s, g['tap_backbone'], rtol=1e-4, atol=2e-4)
+    # coord maps appended in channels 32/33 (acr/model.py:52,340-369)
+    cm = acr_net.coord_maps(128)[0].permute(1, 2, 0)
+    assert torch.equal(x[0, :, :, 32:34], cm) and torch.equal(x[1, :, :, 32:34], cm)
+
+
+def test_forward_matches_reference_end_to_end(engine, frames2):
+    """Vertices/joints within 1e-4 m of the reference (BASELINE.json north_star tolerance)."""
+    g = golden('e2e_batch1.npz')
+    L = pkg('_lib')
+    offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(2, 1)
+    out = engine.forward(torch.from_numpy(frames2).cuda(), offsets=offsets.cuda(), project=True)
+    torch.cuda.synchronize()
+    slots = out['slots'].cpu().numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(slots[b, :, L.SLOT_FLAG] > 0.5, g['f%d_detection_flag' % b].astype(bool))
+        lc, rc = g['f%d_l_centers_pred' % b][0], g['f%d_r_centers_pred' % b][0]
+        assert slots[b, 0, L.SLOT_FLATIND] == lc[1] * 64 + lc[0] and slots[b, 1, L.SLOT_FLATIND] == rc[1] * 64 + rc[0]
+        np.testing.assert_allclose(slots[b, :, L.SLOT_PARAMS:L.SLOT_PARAMS + 109], g['f%d_params_pred' % b], 2e-4, 2e-4)
+        assert np.abs(out['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max() < 1e-4
+        assert np.abs(out['joints'][b].cpu().numpy() - g['f%d_j3d' % b]).max() < 1e-4
+        np.testing.assert_allclose(out['verts_camed'][b].cpu().numpy(), g['f%d_verts_camed' % b], 1e-3, 2e-4)
+        np.testing.assert_allclose(out['pj2d'][b].cpu().numpy(), g['f%d_pj2d' % b], 1e-3, 2e-4)
+        np.testing.assert_allclose(out['pj2d_org'][b].cpu().numpy(), g['f%d_pj2d_org' % b], 1e-3, 5e-2)
+
+
+def test_forward_matches_oracle_and_is_batch_invariant(engine, frames2, oracle_maps, mano_tables):
+    out2 = engine.forward(torch.from_numpy(frames2).cuda())
+    out1 = engine.forward(torch.from_numpy(frames2[1:2]).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out2['verts'][1], out1['verts'][0])        # frames are independent (eval-mode BN)
+    slots = odec.decode(oracle_maps)
+    t = _flip_left(mano_tables)
+    for b in range(2):
+        for h, name in ((0, 'left'), (1, 'right')):
+            v, j, _ = omano.mano_forward(t[name], name, slots['poses'][b, h:h + 1], slots['betas'][b, h:h + 1])
+            assert np.abs(out2['verts'][b, h].cpu().numpy() - v[0]).max() < 1e-4
+            assert np.abs(out2['joints'][b, h].cpu().numpy() - j[0]).max() < 1e-4
+
+
+def test_engine_argument_errors(engine):
+    with pytest.raises(ValueError):
+        engine.forward(torch.zeros(1, 256, 256, 3, dtype=torch.uint8).cuda())
+    with pytest.raises(ValueError):
+        engine.forward(torch.zeros(1, 512, 512, 3).cuda())
