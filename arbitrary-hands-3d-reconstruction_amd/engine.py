@@ -180,7 +180,9 @@ class Engine(object):
         n = len(self.program['ops'])
         ms = (C.c_float * n)()
         _lib.check(self.L.acrmi_profile_ops(self.ctx, _ptr(img), B, ms, n, _stream(self.device)), self.ctx)
-        return [dict(info, ms=float(ms[i])) for i, info in enumerate(self.program['op_info'])]
+        ops = self.program['ops']
+        return [dict(info, ms=float(ms[i]), idx=i, ksize=int(ops[i].ksize), stride=int(ops[i].stride))
+                for i, info in enumerate(self.program['op_info'])]
 
 
 class _DevArray(object):

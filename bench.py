@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""ACR hot-path benchmark: frames/s (2-hand mesh) at 512x512, batch 64 per GPU, HRNet-W32 fp32.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole path (uint8 frames resident in HBM -> backbone -> heads -> decode ->
+MANO -> verts/joints, plus for N>1 the RCCL all-gather of every rank's result slots) over one batch of
+64 synthetic frames per GPU (weak scaling).  Synthetic seeded checkpoint + MANO tables (the real assets
+are not redistributable).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = 'arbitrary-hands-3d-reconstruction_amd'
+
+GFLOP_PER_FRAME = 102.1          # BASELINE.md §3 / SURVEY.md §8d (2*MAC, direct conv + bmm + linear)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
+DOMINANT = 'conv3x3s1_mfma_f32'
+
+
+def pkg(sub):
+    return importlib.import_module(PKG + '.' + sub)
+
+
+def cpu_baseline(sd, tables, n_frames=2):
+    """The oracle (CPU restatement of the reference, oracle/) timed on this box's host cores."""
+    from oracle import acr_net, decode as odec, mano as omano
+    frames = torch.from_numpy(pkg('synth').make_frames(n_frames, seed=3))
+    cores = torch.get_num_threads()
+
+    def run():
+        with torch.no_grad():
+            maps = acr_net.network(sd, frames)
+        slots = odec.decode(maps)
+        for h, name in ((0, 'left'), (1, 'right')):
+            omano.mano_forward(tables[name], name, slots['poses'][:, h], slots['betas'][:, h])
+    run()                                   # warm-up
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    return {'value': n_frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d frames of the same 512x512 workload at batch %d, oracle/ (torch-CPU fp32 restatement), '
+                      '1 warm-up + 1 timed pass (%.1f s)' % (n_frames, n_frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='frames per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    synth, parallel = pkg('synth'), pkg('parallel')
+    B = args.batch
+    sd = synth.make_state_dict(seed=0)
+    tables = synth.make_mano_tables(seed=1)
+    tables['left']['shapedirs'] = tables['left']['shapedirs'].copy()
+    tables['left']['shapedirs'][:, 0, :] *= -1          # acr/mano_wrapper.py:35
+    eng = pkg('engine').Engine(local_rank)
+    eng.load_state_dict(sd, max_batch=B)
+    eng.load_mano(tables)
+    frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False)).cuda()   # resident in HBM
+
+    flat, views = parallel.alloc_result(B, eng.device)
+
+    def step():
+        eng.forward(frames, out=views)
+        if world > 1:
+            return parallel.all_gather_results(flat, B)
+        return views
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        fps = world * B * args.steps / dt
+        # per-op HIP-event timing of the same program on the same stream (one extra pass)
+        prof = eng.profile_ops(frames)
+        L = pkg('_lib')
+        if args.profile_out:
+            with open(args.profile_out, 'w') as f:
+                json.dump(prof, f, indent=0)
+        dom = [p for p in prof if p['kind'] == L.OP_CONV and p['ksize'] == 3 and p['stride'] == 1]
+        dom_ms = sum(p['ms'] for p in dom)
+        dom_flops = sum(p['flops'] for p in dom) * B
+        conv_ms = sum(p['ms'] for p in prof if p['kind'] == L.OP_CONV)
+        total_ms = sum(p['ms'] for p in prof)
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'kernel': DOMINANT, 'launches_per_step': len(dom),
+                    'avg_launch_ms': round(dom_ms / max(1, len(dom)), 4),
+                    'algorithmic_gflop_per_launch': round(dom_flops / max(1, len(dom)) / 1e9, 2),
+                    'share_of_step_ms': round(dom_ms / total_ms, 3),
+                    'whole_path_frac': round(fps / world * GFLOP_PER_FRAME * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                    'all_conv_ms': round(conv_ms, 3), 'all_ops_ms': round(total_ms, 3)}
+        out = {'metric': 'frames/sec (2-hand mesh) at 512x512 batch-64; vertex L2 vs ref', 'value': round(fps, 2),
+               'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
+               'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, fp32',
+                          'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
+                          'gflop_per_frame': GFLOP_PER_FRAME},
+               'roofline': roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(sd, tables)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
