@@ -428,4 +428,9 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "attpool: %s", hipGetErrorString(e));
 }
 
+int acrmi_tune(int key, int value) {
+  if (key == 0) { conv_force_cfg(value); return ACRMI_OK; }
+  return fail(nullptr, ACRMI_EINVAL, "acrmi_tune: unknown key %d", key);
+}
+
 }  // extern "C"

@@ -1,14 +1,21 @@
 // Direct (im2col-free) NHWC fp32 convolution on the gfx950 matrix cores.
 //
-// GEMM view per workgroup: M = TH*TW output pixels of one frame, N = 32*NTW*WAVES_N output channels,
-// K = ks*ks*Cin.  The input patch (with halo) of one Cin chunk is staged once in LDS as
-// [PH][PW][CK+4] (the +4 float pad makes the per-lane ds_read_b128 of 32 neighbouring pixels
-// bank-conflict free); weights are pre-packed on the host in MFMA B-fragment order so a wave
-// fetches one 1 KiB line (global_load_dwordx4, L2 resident, shared by every workgroup) per
-// (tap, 8-channel step, 32-cout tile).  v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate:
+// GEMM view per work item: M = TH*TW output pixels of one frame, N = 32*NTW*WAVES_N output channels,
+// K = ks*ks*Cin.  The input patch (with halo) of one Cin chunk is staged in LDS as [PH][PW][CK+4]
+// (the +4 float pad makes the per-lane ds_read_b128 of 32 neighbouring pixels bank-conflict free);
+// weights are pre-packed on the host in MFMA B-fragment order so a wave fetches one 1 KiB line
+// (global_load_dwordx4, L2 resident, shared by every workgroup) per (tap, 8-channel step, 32-cout tile).
+// v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate:
 //   A[i = lane&31][k = lane>>5] = patch[pixel i][ci = 8s + 4*(lane>>5) + j]
 //   B[k = lane>>5][n = lane&31] = W[cout n][ci = 8s + 4*(lane>>5) + j]          j = 0..3
-// Epilogue fuses folded-BN bias, residual add and ReLU (acr/model.py:483-499, 519-539).
+//
+// Persistent, software-pipelined workgroups: the grid is k workgroups per CU (k chosen so the work
+// items divide evenly), each walks its (tile, N-block, group) items; the global loads of the NEXT
+// (item, Cin-chunk) patch are issued into registers before the MFMAs of the current chunk and only
+// written to LDS after them, so HBM latency never stalls the matrix pipe even when all workgroups
+// of a CU run in lock-step; inside a chunk the A/B fragments of step i+1 are fetched before the
+// 4*MT*NTW MFMAs of step i.  Epilogue fuses folded-BN bias, residual add and ReLU
+// (acr/model.py:483-499, 519-539).
 #include "kernels.h"
 
 namespace acrmi {
@@ -16,11 +23,21 @@ namespace acrmi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static int g_force_cfg = -1;
+void conv_force_cfg(int cfg) { g_force_cfg = cfg; }
+
+struct ConvWork {
+  int tiles_x, tiles_per_frame, n_tiles_total, nblk, total;
+};
+
 template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_mfma_kernel(const ConvArgs a, const ConvWork wk) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4, PAD = KS / 2;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int TP = TH * TW;
+  constexpr int NLOAD = PH * PW * (CK / 4);
+  constexpr int NLD = (NLOAD + NT - 1) / NT;
+  constexpr int TAPS = KS * KS;
   static_assert(TP == 32 * MT * WAVES_M, "tile pixels must equal 32*MT*WAVES_M");
   extern __shared__ f32x4 smem4[];
   float* patch = reinterpret_cast<float*>(smem4);
@@ -28,13 +45,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   const int li = lane & 31, lh = lane >> 5;
-  const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
-  int t = blockIdx.x;
-  const int b = t / (tiles_x * tiles_y);
-  t -= b * tiles_x * tiles_y;
-  const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
-  const int g = blockIdx.z;
-  const int n_tile0 = (blockIdx.y * WAVES_N + wn) * NTW;
 
   f32x16 acc[MT][NTW];
 #pragma unroll
@@ -50,98 +60,199 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
     const int p = (wm * MT + m) * 32 + li;
     aoff[m] = ((p / TW) * S * PW + (p % TW) * S) * CP + 4 * lh;
   }
-  const float* __restrict__ wbase = a.w + (size_t)g * KS * KS * a.cin8 * a.n_tiles * 256 + lane * 4;
-  const float* __restrict__ inb = a.in + (size_t)b * a.H * a.W * a.in_cs + a.in_coff + g * a.Cin;
-  const bool wave_active = n_tile0 < a.n_tiles;   // wave-uniform
-
+  const size_t tap_stride = (size_t)a.cin8 * a.n_tiles * 256;   // floats between taps
+  const size_t step_stride = (size_t)a.n_tiles * 256;
   const int cin_pad = a.cin8 * 8;
-  for (int c0 = 0; c0 < cin_pad; c0 += CK) {
-    __syncthreads();
-    // ---- stage the patch chunk: PH*PW pixels x CK channels, float4 per thread, zero halo ----
-    for (int idx = tid; idx < PH * PW * (CK / 4); idx += NT) {
+
+  f32x4 stage[NLD];
+  auto issue_loads = [&](int w, int c0) {
+    const int tile = w % wk.n_tiles_total;
+    const int g = (w / wk.n_tiles_total) / wk.nblk;
+    const int b = tile / wk.tiles_per_frame;
+    const int t = tile - b * wk.tiles_per_frame;
+    const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
+    const float* __restrict__ inb = a.in + (size_t)b * a.H * a.W * a.in_cs + a.in_coff + g * a.Cin;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * NT;
       const int pix = idx / (CK / 4), c4 = idx % (CK / 4);
-      const int py = pix / PW, px = pix % PW;
-      const int iy = ty0 * S - PAD + py, ix = tx0 * S - PAD + px;
+      const int iy = ty0 * S - PAD + pix / PW, ix = tx0 * S - PAD + pix % PW;
       const int c = c0 + c4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin) {
-        v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * a.W + ix) * a.in_cs + c);
-        if (c + 3 >= a.Cin) {
-          if (c + 1 >= a.Cin) v[1] = 0.f;
-          if (c + 2 >= a.Cin) v[2] = 0.f;
-          v[3] = 0.f;
-        }
-      }
-      *reinterpret_cast<f32x4*>(patch + pix * CP + c4 * 4) = v;
+      const bool ok = (idx < NLOAD) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.Cin;
+      const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      const int cc = c < a.Cin ? c : 0;
+      const int off = (iyc * a.W + ixc) * a.in_cs + cc;   // per-frame offset < 2^31 floats
+      f32x4 v = *reinterpret_cast<const f32x4*>(inb + off);
+      if (c + 1 >= a.Cin) v[1] = 0.f;
+      if (c + 2 >= a.Cin) v[2] = 0.f;
+      if (c + 3 >= a.Cin) v[3] = 0.f;
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      stage[i] = v;
+    }
+  };
+
+  int w = blockIdx.x, c0 = 0;
+  if (w < wk.total) issue_loads(w, 0);
+  while (w < wk.total) {
+    __syncthreads();   // fragment reads of the previous chunk are done
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < NLOAD) *reinterpret_cast<f32x4*>(patch + (idx / (CK / 4)) * CP + (idx % (CK / 4)) * 4) = stage[i];
     }
     __syncthreads();
-    if (!wave_active) continue;
-    const int nsteps = (cin_pad - c0 < CK ? cin_pad - c0 : CK) / 8;
-    const int s0 = c0 / 8;
-    for (int s = 0; s < nsteps; ++s) {
+    // next (item, chunk) of this workgroup: its loads fly while the MFMAs below run
+    int nw = w, nc = c0 + CK;
+    if (nc >= cin_pad) { nc = 0; nw = w + gridDim.x; }
+    if (nw < wk.total) issue_loads(nw, nc);
+
+    const int rest = w / wk.n_tiles_total;
+    const int g = rest / wk.nblk;
+    const int n_tile0 = ((rest % wk.nblk) * WAVES_N + wn) * NTW;
+    const bool wave_active = n_tile0 < a.n_tiles;   // wave-uniform
+    if (wave_active) {
+      const int nsteps = (cin_pad - c0 < CK ? cin_pad - c0 : CK) / 8;
+      const float* __restrict__ wchunk = a.w + (size_t)g * TAPS * tap_stride + (size_t)n_tile0 * 256 + lane * 4 +
+                                         (size_t)(c0 / 8) * step_stride;
+      f32x4 av[2][MT], bv[2][NTW];
 #pragma unroll
-      for (int tap = 0; tap < KS * KS; ++tap) {
-        const int ky = tap / KS, kx = tap % KS;
-        f32x4 av[MT], bv[NTW];
+      for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(patch + aoff[m]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          av[m] = *reinterpret_cast<const f32x4*>(patch + aoff[m] + (ky * PW + kx) * CP + s * 8);
+      for (int n = 0; n < NTW; ++n) bv[0][n] = *reinterpret_cast<const f32x4*>(wchunk + (size_t)n * 256);
+      for (int s = 0; s < nsteps; ++s) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          bv[n] = *reinterpret_cast<const f32x4*>(
-              wbase + ((size_t)(tap * a.cin8 + s0 + s) * a.n_tiles + n_tile0 + n) * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int cur = tap & 1, nxt = cur ^ 1;
+          // prefetch fragments of the next (s, tap); the last step re-reads a valid address
+          const int ntap = tap + 1 < TAPS ? tap + 1 : 0;
+          const int ns = tap + 1 < TAPS ? s : (s + 1 < nsteps ? s + 1 : s);
+          const int nky = ntap / KS, nkx = ntap % KS;
 #pragma unroll
           for (int m = 0; m < MT; ++m)
+            av[nxt][m] = *reinterpret_cast<const f32x4*>(patch + aoff[m] + (nky * PW + nkx) * CP + ns * 8);
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j], bv[n][j], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NTW; ++n)
+            bv[nxt][n] = *reinterpret_cast<const f32x4*>(wchunk + (size_t)ntap * tap_stride +
+                                                         (size_t)ns * step_stride + (size_t)n * 256);
+          // keep the prefetch ahead of this step's MFMAs (the scheduler otherwise sinks the loads to
+          // just before their first use and the L2 latency is exposed every step)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int n = 0; n < NTW; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m][j], bv[cur][n][j], acc[m][n], 0, 0, 0);
+        }
+        if (TAPS & 1) {   // odd tap count: the double buffer parity flips every s; re-align
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[0][m] = av[1][m];
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) bv[0][n] = bv[1][n];
+        }
       }
-    }
-  }
-  if (!wave_active) return;
-  // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
-  const float* __restrict__ bias = a.bias + (size_t)g * a.n_tiles * 32 + (size_t)b * a.bias_fstride;
+      if (c0 + CK >= cin_pad) {
+        // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
+        const int tile = w % wk.n_tiles_total;
+        const int b = tile / wk.tiles_per_frame;
+        const int t = tile - b * wk.tiles_per_frame;
+        const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
+        const float* __restrict__ bias = a.bias + (size_t)g * a.n_tiles * 32 + (size_t)b * a.bias_fstride;
+        const bool full_tile = (ty0 + TH <= a.Ho) && (tx0 + TW <= a.Wo);
+        const bool has_res = a.res != nullptr;
+        // per-frame bases (uniform -> SGPRs) + 32-bit per-lane offsets
+        float* __restrict__ outb = a.out + (size_t)b * a.Ho * a.Wo * a.out_cs + a.out_coff + g * a.Cout;
+        const float* __restrict__ resb =
+            has_res ? a.res + (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout : nullptr;
 #pragma unroll
-  for (int n = 0; n < NTW; ++n) {
-    const int co = (n_tile0 + n) * 32 + li;
-    if (co >= a.Cout) continue;
-    const float bv = bias[co];
+        for (int n = 0; n < NTW; ++n) {
+          const int co = (n_tile0 + n) * 32 + li;
+          const bool cok = co < a.Cout;
+          const float bvv = cok ? bias[co] : 0.f;
+          const int coc = cok ? co : 0;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+          for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-        if (oy < a.Ho && ox < a.Wo) {
-          const size_t pix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
-          float v = acc[m][n][r] + bv;
-          if (a.res) v += a.res[pix * a.res_cs + a.res_coff + g * a.Cout + co];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[pix * a.out_cs + a.out_coff + g * a.Cout + co] = v;
+            for (int half = 0; half < 2; ++half) {
+              int pix[8];
+              bool ok[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int r = half * 8 + q;
+                const int p = (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int oy = ty0 + p / TW, ox = tx0 + p % TW;
+                ok[q] = cok && (full_tile || (oy < a.Ho && ox < a.Wo));
+                oy = oy < a.Ho ? oy : a.Ho - 1;
+                ox = ox < a.Wo ? ox : a.Wo - 1;
+                pix[q] = oy * a.Wo + ox;
+              }
+              float rv[8];
+              if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rv[q] = resb[pix[q] * a.res_cs + coc];
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int r = half * 8 + q;
+                float v = acc[m][n][r] + bvv;
+                if (has_res) v += rv[q];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (ok[q]) outb[pix[q] * a.out_cs + co] = v;
+                acc[m][n][r] = 0.f;
+              }
+            }
+          }
         }
       }
     }
+    w = nw;
+    c0 = nc;
   }
 }
+
+static int g_num_cus = 0;
 
 template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr size_t lds = (size_t)PH * PW * (CK + 4) * sizeof(float);
+  constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
   auto kern = conv_mfma_kernel<KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int occ = 0;
+  if (!occ) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (!g_num_cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+      if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+      g_num_cus = prop.multiProcessorCount;
+    }
+    int o = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, NTHREADS, lds);
+    if (e != hipSuccess) return e;
+    occ = o < 1 ? 1 : (o > 4 ? 4 : o);
   }
-  const int tiles = ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH) * a.B;
-  const int nblk = (a.n_tiles + WAVES_N * NTW - 1) / (WAVES_N * NTW);
-  dim3 grid(tiles, nblk, a.groups);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  ConvWork wk;
+  wk.tiles_x = (a.Wo + TW - 1) / TW;
+  wk.tiles_per_frame = wk.tiles_x * ((a.Ho + TH - 1) / TH);
+  wk.n_tiles_total = wk.tiles_per_frame * a.B;
+  wk.nblk = (a.n_tiles + WAVES_N * NTW - 1) / (WAVES_N * NTW);
+  wk.total = wk.n_tiles_total * wk.nblk * a.groups;
+  // k workgroups per CU, k <= occupancy, minimising the busiest CU's item count (ties -> larger k)
+  int best_k = 1;
+  long best_cost = -1;
+  for (int k = 1; k <= occ; ++k) {
+    const long slots = (long)g_num_cus * k;
+    const long cost = ((wk.total + slots - 1) / slots) * k;
+    if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_k = k; }
+  }
+  long grid = (long)g_num_cus * best_k;
+  if (grid > wk.total) grid = wk.total;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, a, wk);
   return hipGetLastError();
 }
 
@@ -152,6 +263,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.ks == 3 && a.stride == 1) {
     if (n32) return small ? launch_cfg<3, 1, 8, 16, 4, 1, 1, 1, 32>(a, s) : launch_cfg<3, 1, 16, 16, 4, 2, 1, 1, 32>(a, s);
+    if (g_force_cfg == 1) return launch_cfg<3, 1, 8, 16, 2, 2, 2, 1, 32>(a, s);
     return small ? launch_cfg<3, 1, 8, 16, 2, 2, 2, 1, 32>(a, s) : launch_cfg<3, 1, 16, 16, 4, 2, 1, 2, 32>(a, s);
   }
   if (a.ks == 3 && a.stride == 2) {

@@ -24,6 +24,7 @@ struct ConvArgs {
 // returns hipSuccess or the launch error; cout tiles etc. derived inside
 hipError_t launch_conv(ConvArgs a, hipStream_t s);
 const char* conv_kernel_name(const ConvArgs& a);
+void conv_force_cfg(int cfg);
 
 hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStream_t s);
 hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,

@@ -170,6 +170,10 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
  * (one untimed warm-up pass first).  ms_out[n_ops]; returns n_ops or <0. */
 int acrmi_profile_ops(acrmi_ctx* ctx, const uint8_t* img_dev, int B, float* ms_out, int n_ms, void* stream);
 
+/* Tuning hook for kernel experiments (tools/conv_bench.py): key 0 = force a conv tile config id
+ * (-1 = automatic selection).  Not part of the reference-facing surface. */
+int acrmi_tune(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif
