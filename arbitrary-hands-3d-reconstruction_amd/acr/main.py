@@ -1,0 +1,138 @@
+"""acr.main.ACR: the demo-facing wrapper (acr/main.py:24-141) over the MI355X path.
+
+    acr = ACR(args_set)                      # builds the model, loads the checkpoint + MANO tables
+    results = acr(bgr_frame, path)           # {path: [per-hand dict of float16 arrays]}  or  {path: {}}
+    results = acr.forward_batch(frames, paths)   # the batched form the reference never had
+
+Rendering / video IO (acr/visualization.py, acr/renderer/*) are out of scope: results are returned,
+nothing is drawn.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from ..config import ConfigContext, args, parse_args, validate
+from .mano_wrapper import MANOWrapper
+from .model import ACR as ACR_v1
+from .utils import (create_OneEuroFilter, get_remove_keys, img_preprocess, justify_detection_state, load_model,
+                    reorganize_results, save_results, smooth_results)
+
+
+class ACR(object):
+    def __init__(self, args_set=None, state_dict=None, mano_tables=None, device=0, max_batch=1):
+        """args_set: namespace from config.parse_args (default: config.args()).  state_dict / mano_tables
+        let callers inject in-memory assets (tests, synthetic runs) instead of model_path / mano_root files."""
+        a = validate(args() if args_set is None else args_set)
+        self.demo_cfg = {'mode': 'parsing', 'calc_loss': False}
+        for k, v in vars(a).items():
+            setattr(self, k, v)
+        logging.basicConfig(level=logging.INFO)
+        if self.temporal_optimization:
+            self.filter_dict = {0: create_OneEuroFilter(a.smooth_coeff), 1: create_OneEuroFilter(a.smooth_coeff)}
+        self._args = a
+        self._build_model_(state_dict, mano_tables, device, max_batch)
+
+    def _build_model_(self, state_dict, mano_tables, device, max_batch):
+        """acr/main.py:57-63"""
+        with ConfigContext(self._args):
+            model = ACR_v1(device=device, max_batch=max_batch).eval()
+            if state_dict is not None:
+                model.load_state_dict(state_dict)
+            else:
+                model = load_model(self.model_path, model, prefix='module.', drop_prefix='', fix_loaded=False)
+            self.model = model.cuda(device)
+            self.mano_regression = MANOWrapper(mano_root=self.mano_root, tables=mano_tables, device=device,
+                                               engine=self.model.engine())
+
+    @torch.no_grad()
+    def process_results(self, outputs):
+        """acr/main.py:66-89"""
+        if self.temporal_optimization:
+            pd = outputs['params_dict']
+            if len(pd['poses']) != 2:
+                raise ValueError('temporal optimisation expects exactly one frame (2 rows), as acr/main.py:77 asserts')
+            for sid, flag in enumerate(outputs['detection_flag_cache']):
+                if flag:                                        # row index == hand type at batch 1
+                    p, b = smooth_results(self.filter_dict[sid], pd['poses'][sid].cpu(), pd['betas'][sid].cpu())
+                    pd['poses'][sid], pd['betas'][sid] = p.to(pd['poses'].device), b.to(pd['betas'].device)
+        outputs = self.mano_regression(outputs, outputs['meta_data'])
+        reorganize_idx = outputs['reorganize_idx'].cpu().numpy()
+        results = reorganize_results(outputs, outputs['meta_data']['imgpath'], reorganize_idx)
+        return outputs, results
+
+    @torch.no_grad()
+    def single_image_forward(self, bgr_frame, path):
+        """acr/main.py:126-141"""
+        meta = img_preprocess(bgr_frame, path, input_size=self.input_size, single_img_input=True)
+        ds_org, imgpath_org = get_remove_keys(meta, keys=['data_set', 'imgpath'])
+        meta['batch_ids'] = torch.arange(len(meta['image']))
+        outputs = self.model(meta, **self.demo_cfg)
+        outputs['detection_flag'], outputs['reorganize_idx'] = justify_detection_state(outputs['detection_flag'],
+                                                                                       outputs['reorganize_idx'])
+        meta.update({'imgpath': imgpath_org, 'data_set': ds_org})
+        outputs['meta_data']['imgpath'] = [path] * len(outputs['params_pred'])
+        return outputs
+
+    @torch.no_grad()
+    def forward(self, bgr_frame, path):
+        """acr/main.py:92-123 without the drawing: {path: [hand dicts]} or {path: {}} when nothing is detected."""
+        outputs = self.single_image_forward(bgr_frame, path)
+        if outputs is not None and outputs['detection_flag']:
+            outputs, results = self.process_results(outputs)
+            if self.save_dict_results and self.output_dir:
+                save_results(results, self.output_dir.rstrip('/') + '/results.pkl')
+        else:
+            print('no hand detected!')
+            results = {path: {}}
+        return results
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def forward_batch(self, rgb_u8_frames, paths, offsets=None):
+        """Batched throughput path: uint8 [B,512,512,3] RGB (already pre-processed) -> per-image results.
+        One fused call (backbone, heads, decode, MANO, projection) + one D2H of the packed results."""
+        eng = self.model.engine(rgb_u8_frames.shape[0])
+        B = rgb_u8_frames.shape[0]
+        if offsets is None:
+            offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(B, 1)
+        out = eng.forward(rgb_u8_frames, offsets=offsets, project=True)
+        slots = out['slots'].cpu().numpy()
+        host = {k: out[k].cpu().numpy() for k in ('verts', 'joints', 'pj2d', 'pj2d_org')}
+        from .. import _lib as S
+        results = {}
+        for b, path in enumerate(paths):
+            hands = []
+            for h in (0, 1):
+                if slots[b, h, S.SLOT_FLAG] > 0.5:
+                    s = slots[b, h]
+                    hands.append({'cam': s[S.SLOT_CAM:S.SLOT_CAM + 3].astype(np.float16),
+                                  'poses': s[S.SLOT_POSES:S.SLOT_POSES + 48].astype(np.float16),
+                                  'betas': s[S.SLOT_BETAS:S.SLOT_BETAS + 10].astype(np.float16),
+                                  'j3d': host['joints'][b, h].astype(np.float16),
+                                  'verts': host['verts'][b, h].astype(np.float16),
+                                  'pj2d': host['pj2d'][b, h].astype(np.float16),
+                                  'pj2d_org': host['pj2d_org'][b, h].astype(np.float16),
+                                  'hand_type': np.int32(h), 'detection_flag_cache': True})
+            results[path] = hands if hands else {}
+        return results
+
+
+def main(argv=None):
+    """python -m <package>.acr.main --demo_mode folder --inputs DIR : runs the path on .npy / image files it can
+    read without cv2 (uint8 HxWx3 BGR arrays saved with numpy)."""
+    import glob
+    import os
+    import sys
+    a = parse_args(sys.argv[1:] if argv is None else argv)
+    with ConfigContext(a):
+        acr = ACR(args_set=a)
+        files = sorted(glob.glob(os.path.join(a.inputs or '.', '*.npy')))
+        for f in files:
+            res = acr(np.load(f), f)
+            print(f, {k: (len(v) if isinstance(v, list) else 0) for k, v in res.items()})
+
+
+if __name__ == '__main__':
+    main()

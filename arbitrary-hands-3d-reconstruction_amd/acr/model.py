@@ -1,0 +1,115 @@
+"""acr.model.ACR with the reference's surface (acr/model.py:23-44): no-arg constructor,
+state_dict()/load_state_dict() with the reference's key names, eval()/cuda(), and
+forward(meta_data, **cfg) -> the reference's output dict.  All arithmetic runs in libacrmi.so
+through Engine; this class holds the checkpoint on the host and the resident engine on one GPU.
+"""
+from collections import OrderedDict
+
+import torch
+
+from ..config import args, validate
+from ..engine import Engine
+from ..schema import state_dict_schema
+from .result_parser import ResultParser, rows_from_slots
+
+
+class ACR(object):
+    def __init__(self, device=0, max_batch=1, **kwargs):
+        validate(args())
+        self._result_parser = ResultParser()
+        self.params_num = self._result_parser.params_num
+        self._sd = OrderedDict()
+        for k, shp in state_dict_schema().items():       # zero-initialised until a checkpoint is loaded
+            self._sd[k] = torch.zeros(shp, dtype=torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
+        for k in self._sd:
+            if k.endswith('running_var') or (k.endswith('.weight') and (k[:-7] + '.running_var') in self._sd):
+                self._sd[k].fill_(1.0)
+        self._device = device
+        self._max_batch = max_batch
+        self._engine = None
+        self._loaded = False
+        self.training = False
+
+    # ---- nn.Module-like surface ----------------------------------------------------------------
+    def state_dict(self):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, sd, strict=True):
+        from ..packer import strip_prefix, check_state_dict
+        sd = strip_prefix(sd)
+        if strict:
+            check_state_dict(sd)
+        missing = [k for k in self._sd if k not in sd]
+        unexpected = [k for k in sd if k not in self._sd]
+        for k, v in sd.items():
+            if k in self._sd:
+                t = v.detach().cpu() if hasattr(v, 'detach') else torch.as_tensor(v)
+                if tuple(t.shape) != tuple(self._sd[k].shape) and t.numel() == self._sd[k].numel():
+                    t = t.reshape(self._sd[k].shape)
+                if tuple(t.shape) != tuple(self._sd[k].shape):
+                    raise ValueError('size mismatch for %s: %s vs %s' % (k, tuple(t.shape), tuple(self._sd[k].shape)))
+                self._sd[k] = t.to(self._sd[k].dtype).clone()
+        self._loaded = True
+        self._engine = None            # re-pack on next use
+        return missing, unexpected
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise ValueError('inference only: the reference ships no training code either')
+        return self
+
+    def cuda(self, device=None):
+        if device is not None:
+            self._device = device if isinstance(device, int) else (torch.device(device).index or 0)
+        self.engine()
+        return self
+
+    def to(self, device):
+        return self.cuda(device)
+
+    def engine(self, min_batch=1):
+        if self._engine is None:
+            self._engine = Engine(self._device)
+            self._engine.load_state_dict(self._sd, max_batch=max(self._max_batch, min_batch))
+        else:
+            self._engine.ensure_batch(min_batch)
+        return self._engine
+
+    # ---- the reference's forward ----------------------------------------------------------------
+    @torch.no_grad()
+    def backbone(self, image):
+        """acr/model.py:831-865: uint8 [B,512,512,3] -> [B,32,128,128] (NCHW copy of the resident buffer)."""
+        eng = self.engine(image.shape[0])
+        B = eng.backbone_heads(image)
+        return eng.buffer(eng.program['heads'].backbone_buf, B, 32).permute(0, 3, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def head_forward(self, image):
+        """acr/model.py:47-65 (takes the frames, not backbone features: the network is one resident program)."""
+        eng = self.engine(image.shape[0])
+        B = eng.backbone_heads(image)
+        return eng.head_maps(B)
+
+    @torch.no_grad()
+    def forward(self, meta_data, **cfg):
+        """meta_data: {'image': uint8 [B,512,512,3] RGB, 'offsets': [B,10], 'batch_ids': [B], ...};
+        cfg (mode/calc_loss) is accepted and ignored like the reference does in eval (acr/model.py:32-44).
+        cfg['return_maps']=False skips the NCHW copies of the head maps."""
+        img = meta_data['image']
+        if img.dtype != torch.uint8:
+            img = img.to(torch.uint8)
+        eng = self.engine(img.shape[0])
+        B = eng.backbone_heads(img.contiguous())
+        outputs = eng.head_maps(B) if cfg.get('return_maps', True) else {}
+        outputs['slots'] = eng.decode(B)
+        if 'batch_ids' not in meta_data:
+            meta_data['batch_ids'] = torch.arange(B)
+        outputs.update(rows_from_slots(outputs['slots'], meta_data, self._result_parser.map_size))
+        outputs['meta_data'] = meta_data
+        return outputs
+
+    __call__ = forward

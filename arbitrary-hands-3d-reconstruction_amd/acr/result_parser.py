@@ -1,0 +1,98 @@
+"""ResultParser: the reference's parse() contract (acr/result_parser.py:21-40,85-190) over the HIP
+decode kernel.  The kernel writes fixed per-(frame,hand) slots; this module re-packs them into the
+reference's variable-length rows: all left rows (ascending frame), then all right rows.
+
+Semantics are per frame (= the reference run at batch 1 for every frame, the only way
+acr/main.py:126-141 calls it).  The reference's batch>1 quirks - prior gated on *every* flag of the
+batch (:131), determine_coeff reading row 0 only (:42-47) - are not reproduced.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..config import args
+
+PART_IDX = [3, 6, 90, 10]     # cam, global_orient (6D), hand_pose (15x6D), betas  (acr/result_parser.py:12)
+
+
+def rows_from_slots(slots, meta_data=None, map_size=64):
+    """slots [B,2,176] (any device) -> dict of the row tensors parse_maps/parse produce.
+    A side with no detection in the whole batch keeps ONE placeholder row (frame 0, pixel 0,
+    detection_flag False), as acr/result_parser.py:102-120 does."""
+    dev = slots.device
+    B = slots.shape[0]
+    flag = slots[:, :, _lib.SLOT_FLAG] > 0.5
+    out = {}
+    ids, flags = [], []
+    for h in (0, 1):
+        idx = torch.nonzero(flag[:, h]).flatten()
+        if idx.numel() == 0:
+            idx = torch.zeros(1, dtype=torch.long, device=dev)
+            flags.append(torch.zeros(1, device=dev))
+        else:
+            flags.append(torch.ones(idx.numel(), device=dev))
+        ids.append(idx)
+    rows = torch.cat([slots[ids[0], 0], slots[ids[1], 1]], 0)            # [H,176]
+    L, R = ids[0].numel(), ids[1].numel()
+    batch_ids = torch.cat(ids)
+    S = _lib
+    out['l_params_pred'] = rows[:L, S.SLOT_PARAMS:S.SLOT_PARAMS + 109]
+    out['r_params_pred'] = rows[L:, S.SLOT_PARAMS:S.SLOT_PARAMS + 109]
+    out['params_pred'] = rows[:, S.SLOT_PARAMS:S.SLOT_PARAMS + 109].contiguous()
+    out['detection_flag'] = torch.cat(flags)
+    out['detection_flag_cache'] = out['detection_flag'].bool()
+    flat = rows[:, S.SLOT_FLATIND].long()
+    centers = torch.stack([flat % map_size, torch.div(flat, map_size, rounding_mode='floor')], 1)   # (x, y)
+    out['l_centers_pred'], out['r_centers_pred'] = centers[:L], centers[L:]
+    conf = rows[:, S.SLOT_SCORE:S.SLOT_SCORE + 1]
+    out['l_centers_conf'], out['r_centers_conf'] = conf[:L], conf[L:]
+    out['left_hand_num'] = torch.tensor([L], device=dev)
+    out['right_hand_num'] = torch.tensor([R], device=dev)
+    out['output_hand_type'] = torch.cat((torch.zeros(L), torch.ones(R))).to(dev).to(torch.int32)
+    poses = rows[:, S.SLOT_POSES:S.SLOT_POSES + 48].contiguous()
+    out['params_dict'] = {'cam': rows[:, S.SLOT_CAM:S.SLOT_CAM + 3].contiguous(),
+                          'global_orient': poses[:, :3].contiguous(), 'hand_pose': poses[:, 3:].contiguous(),
+                          'betas': rows[:, S.SLOT_BETAS:S.SLOT_BETAS + 10].contiguous(), 'poses': poses}
+    if meta_data is not None:
+        bid = meta_data['batch_ids'].to(dev) if 'batch_ids' in meta_data else torch.arange(B, device=dev)
+        out['reorganize_idx'] = bid[batch_ids]
+        for key in ('image', 'offsets', 'imgpath'):          # acr/result_parser.py:186-187
+            if key in meta_data:
+                v = meta_data[key]
+                if isinstance(v, torch.Tensor):
+                    meta_data[key] = v[batch_ids.to(v.device)]
+                elif isinstance(v, list):
+                    meta_data[key] = np.array(v)[batch_ids.cpu().numpy()]
+    out['_batch_ids'] = batch_ids
+    return out
+
+
+class ResultParser(object):
+    def __init__(self):
+        a = args()
+        self.map_size = a.centermap_size
+        self.part_name = ['cam', 'global_orient', 'hand_pose', 'betas']
+        self.part_idx = [a.cam_dim, a.rot_dim, (a.mano_theta_num - 1) * a.rot_dim, 10]
+        self.kps_num = 21
+        self.params_num = int(np.array(self.part_idx).sum())
+        if self.part_idx != PART_IDX:
+            raise ValueError('only the 3/6/90/10 parameter split is implemented')
+
+    @torch.no_grad()
+    def parse(self, outputs, meta_data, cfg):
+        """outputs: dict with l/r_center_map [B,1,64,64], l/r_params_maps [B,109,64,64],
+        l/r_prior_maps [B,106,64,64] (NCHW device tensors, as acr.model.ACR.head_forward returns) -
+        or a ready 'slots' tensor from the fused path.  Mutates and returns (outputs, meta_data)."""
+        if 'slots' in outputs:
+            slots = outputs['slots']
+        else:
+            from .. import ops
+            m = {k: ops.to_nhwc(outputs[k], device=outputs[k].device) for k in
+                 ('l_center_map', 'r_center_map', 'l_params_maps', 'r_params_maps', 'l_prior_maps', 'r_prior_maps')}
+            slots = ops.decode_maps(m['l_center_map'], m['r_center_map'], m['l_params_maps'], m['r_params_maps'],
+                                    m['l_prior_maps'], m['r_prior_maps'])
+            outputs['slots'] = slots
+        outputs.update(rows_from_slots(slots, meta_data, self.map_size))
+        return outputs, meta_data
+
+    __call__ = parse

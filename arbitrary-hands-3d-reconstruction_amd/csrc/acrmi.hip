@@ -335,9 +335,11 @@ int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* b
   if (H == 0) return ACRMI_OK;    // ManoLayer accepts N == 0 (acr/mano_wrapper.py:43 comment)
   if (H < 0 || !poses || !betas || !verts || !joints || center_idx >= 21)
     return fail(c, ACRMI_EINVAL, "acrmi_mano: bad arguments");
-  if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_mano: MANO tables not loaded");
+  if (!c->have_mano[0] && !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_mano: MANO tables not loaded");
   ManoArgs m{};
-  m.t[0] = c->mano[0]; m.t[1] = c->mano[1];
+  // a context may hold one side only (a lone ManoLayer); rows must then all be of that side
+  m.t[0] = c->have_mano[0] ? c->mano[0] : c->mano[1];
+  m.t[1] = c->have_mano[1] ? c->mano[1] : c->mano[0];
   m.poses = poses; m.pose_stride = pose_stride; m.betas = betas; m.beta_stride = beta_stride;
   m.side = side; m.H = H; m.center_idx = center_idx;
   m.verts = verts; m.joints = joints; m.center = center;

@@ -67,16 +67,22 @@ class Engine(object):
     def load_mano(self, tables):
         """tables: {'left': {...}, 'right': {...}} numpy arrays as registered by mano/manolayer.py:61-102.
         The left-hand shapedirs x-flip (acr/mano_wrapper.py:35) must already be applied by the caller."""
-        for side, name in ((0, 'left'), (1, 'right')):
-            t = tables[name]
-            arrs = [np.ascontiguousarray(np.asarray(t[k], np.float32)) for k in
-                    ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'hands_mean')]
-            shapes = [(778, 3), (778, 3, 10), (778, 3, 135), (16, 778), (778, 16), (45,)]
-            for a, s in zip(arrs, shapes):
-                if a.shape != s and a.reshape(-1).shape != (int(np.prod(s)),):
-                    raise ValueError('MANO table has shape %s, expected %s' % (a.shape, s))
-            _lib.check(self.L.acrmi_load_mano(self.ctx, side, *[a.ctypes.data_as(C.c_void_p) for a in arrs]), self.ctx)
+        for name in ('left', 'right'):
+            self.load_mano_side(name, tables[name])
         self.have_mano = True
+
+    def load_mano_side(self, name, t):
+        """One side's tables (mano/manolayer.py:61-102 buffers) -> HBM, blend-shape tables transposed."""
+        side = {'left': 0, 'right': 1}[name]
+        arrs = [np.ascontiguousarray(np.asarray(t[k], np.float32)) for k in
+                ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'hands_mean')]
+        shapes = [(778, 3), (778, 3, 10), (778, 3, 135), (16, 778), (778, 16), (45,)]
+        for a, s in zip(arrs, shapes):
+            if a.shape != s and a.reshape(-1).shape != (int(np.prod(s)),):
+                raise ValueError('MANO table has shape %s, expected %s' % (a.shape, s))
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()      # tables may be replaced while earlier launches still read them
+            _lib.check(self.L.acrmi_load_mano(self.ctx, side, *[a.ctypes.data_as(C.c_void_p) for a in arrs]), self.ctx)
 
     # ---- hot path ------------------------------------------------------------------------------
     def _check_img(self, img):

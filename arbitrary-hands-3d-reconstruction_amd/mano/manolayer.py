@@ -1,0 +1,153 @@
+"""ManoLayer: the reference's constructor/forward signature (mano/manolayer.py:13-22,104-110,273-276)
+over the fused HIP MANO kernel.  Buffers (th_faces, th_v_template, ...) are host tensors for callers
+such as the visualiser (acr/visualization.py:80,120); the arithmetic runs in libacrmi.so.
+"""
+import io
+import os
+import pickle
+
+import numpy as np
+import torch
+
+_SHARED = {}       # device index -> Engine used for MANO-only calls
+
+
+def shared_engine(device=0):
+    from ..engine import Engine
+    if device not in _SHARED:
+        _SHARED[device] = Engine(device)
+    return _SHARED[device]
+
+
+class _Stub(object):
+    """Stands in for chumpy classes when unpickling MANO_*.pkl without chumpy installed."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {'state': state})
+
+    @property
+    def r(self):
+        for key in ('x', 'a'):
+            if key in self.__dict__:
+                return np.asarray(self.__dict__[key])
+        raise AttributeError('cannot recover array from chumpy stub')
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith('chumpy'):
+            return _Stub
+        return super().find_class(module, name)
+
+
+def _arr(v):
+    if isinstance(v, _Stub):
+        v = v.r
+    if hasattr(v, 'toarray'):
+        v = v.toarray()
+    return np.asarray(v)
+
+
+def load_mano_pkl(path):
+    """mano/manolayer.py:350-394 (ready_arguments) without chumpy: returns the float32 tables."""
+    if not os.path.exists(path):
+        raise FileNotFoundError('%s not found: the MANO model files are licence gated (reference README.md:36); '
+                                'pass tables= for synthetic tables' % path)
+    with open(path, 'rb') as f:
+        dd = _Unpickler(io.BytesIO(f.read()), encoding='latin1').load()
+    return {'v_template': _arr(dd['v_template']).astype(np.float32),
+            'shapedirs': _arr(dd['shapedirs']).astype(np.float32),
+            'posedirs': _arr(dd['posedirs']).astype(np.float32),
+            'J_regressor': _arr(dd['J_regressor']).astype(np.float32),
+            'weights': _arr(dd['weights']).astype(np.float32),
+            'hands_mean': _arr(dd['hands_mean']).astype(np.float32),
+            'hands_components': _arr(dd['hands_components']).astype(np.float32),
+            'faces': _arr(dd['f']).astype(np.int64),
+            'kintree_table': _arr(dd['kintree_table']).astype(np.int64)}
+
+
+class ManoLayer(object):
+    def __init__(self, center_idx=None, flat_hand_mean=True, ncomps=6, side='right', mano_root='model_data/mano/',
+                 use_pca=True, root_rot_mode='axisang', joint_rot_mode='axisang', robust_rot=False, tables=None,
+                 device=0):
+        if use_pca or root_rot_mode != 'axisang' or joint_rot_mode != 'axisang':
+            raise ValueError('only use_pca=False with axis-angle rotations is implemented '
+                             '(the configuration acr/mano_wrapper.py:17-35 uses)')
+        if side not in ('left', 'right'):
+            raise ValueError('side must be "left" or "right"')
+        self.center_idx, self.side, self.use_pca, self.ncomps = center_idx, side, False, 45
+        self.flat_hand_mean, self.rot, self.robust_rot = flat_hand_mean, 3, robust_rot
+        self.root_rot_mode, self.joint_rot_mode = root_rot_mode, joint_rot_mode
+        if tables is None:
+            self.mano_path = os.path.join(mano_root, 'MANO_RIGHT.pkl' if side == 'right' else 'MANO_LEFT.pkl')
+            tables = load_mano_pkl(self.mano_path)
+        t = {k: np.asarray(v) for k, v in tables.items()}
+        self.th_betas = torch.zeros(1, 10)
+        self.th_shapedirs = torch.from_numpy(t['shapedirs'].astype(np.float32).copy())
+        self.th_posedirs = torch.from_numpy(t['posedirs'].astype(np.float32).copy())
+        self.th_v_template = torch.from_numpy(t['v_template'].astype(np.float32).copy()).unsqueeze(0)
+        self.th_J_regressor = torch.from_numpy(t['J_regressor'].astype(np.float32).copy())
+        self.th_weights = torch.from_numpy(t['weights'].astype(np.float32).copy())
+        self.th_faces = torch.from_numpy(t['faces'].astype(np.int64).copy())
+        hm = np.zeros(45, np.float32) if flat_hand_mean else t['hands_mean'].astype(np.float32)
+        self.th_hands_mean = torch.from_numpy(hm.copy()).unsqueeze(0)
+        if 'hands_components' in t:
+            self.th_comps = torch.from_numpy(t['hands_components'].astype(np.float32).copy())
+        kt = t.get('kintree_table')
+        self.kintree_parents = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14] if kt is None else list(kt[0].tolist())
+        self._device = device
+        self._engine = None
+        self._dirty = True
+
+    # the reference is an nn.Module; keep the calls user code makes on it
+    def cuda(self, device=None):
+        if device is not None:
+            self._device = device if isinstance(device, int) else torch.device(device).index or 0
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def sync(self, engine=None):
+        """(Re-)upload this side's tables; call after editing a th_* buffer (acr/mano_wrapper.py:35)."""
+        eng = engine or shared_engine(self._device)
+        eng.load_mano_side(self.side, self.tables())
+        self._engine = eng
+        self._dirty = False
+
+    def tables(self):
+        return {'v_template': self.th_v_template[0].numpy(), 'shapedirs': self.th_shapedirs.numpy(),
+                'posedirs': self.th_posedirs.numpy(), 'J_regressor': self.th_J_regressor.numpy(),
+                'weights': self.th_weights.numpy(), 'hands_mean': self.th_hands_mean[0].numpy()}
+
+    def forward(self, th_pose_coeffs, th_betas=torch.zeros(1), th_trans=torch.zeros(1), root_palm=torch.Tensor([0]),
+                share_betas=torch.Tensor([0])):
+        """-> (verts [N,778,3], joints [N,21,3], center_joint [N,1,3]) in metres (mano/manolayer.py:269-276)."""
+        if bool(root_palm):
+            raise ValueError('root_palm=True is not implemented')
+        if self._dirty or self._engine is None:
+            self.sync(self._engine)
+        eng = self._engine
+        N = th_pose_coeffs.shape[0]
+        if th_betas is None or th_betas.numel() == 1:
+            th_betas = self.th_betas.expand(N, 10)
+        elif bool(share_betas):
+            th_betas = th_betas.mean(0, keepdim=True).expand(N, 10)
+        use_trans = not (th_trans is None or bool(torch.norm(th_trans.float()) == 0))
+        side = torch.full((N,), 0 if self.side == 'left' else 1, dtype=torch.int32)
+        cidx = None if use_trans else self.center_idx
+        verts, joints, center, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=cidx)
+        if use_trans:
+            t = th_trans.to(verts.device).float().unsqueeze(1)
+            return verts + t, joints + t, t
+        if self.center_idx is None:
+            return verts, joints, None
+        return verts, joints, center
+
+    __call__ = forward

@@ -1,0 +1,144 @@
+"""CPU tests of the host logic that mirrors the reference's Python surface: slot -> row re-packing,
+config validation, packer invariants, pre-processing, smoothing, camera translation."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import golden, pkg
+from oracle import decode as odec
+
+
+def _slots_tensor(s):
+    """oracle slots dict -> [B,2,176] tensor in the library's slot layout."""
+    L = pkg('_lib')
+    B = s['flag'].shape[0]
+    t = torch.zeros(B, 2, L.SLOT)
+    t[:, :, L.SLOT_FLAG] = torch.from_numpy(s['flag'].astype(np.float32))
+    t[:, :, L.SLOT_FLATIND] = torch.from_numpy(s['flat_ind'].astype(np.float32))
+    t[:, :, L.SLOT_SCORE] = torch.from_numpy(s['score'])
+    t[:, :, L.SLOT_CAM:L.SLOT_CAM + 3] = torch.from_numpy(s['cam'])
+    t[:, :, L.SLOT_POSES:L.SLOT_POSES + 48] = torch.from_numpy(s['poses'])
+    t[:, :, L.SLOT_BETAS:L.SLOT_BETAS + 10] = torch.from_numpy(s['betas'])
+    t[:, :, L.SLOT_PARAMS:L.SLOT_PARAMS + 109] = torch.from_numpy(s['params_pred'])
+    return t
+
+
+@pytest.mark.parametrize('name', list(cases.DECODE_CASES))
+def test_rows_from_slots_reproduces_reference_dict(name):
+    """Row order (left rows then right rows), placeholder rows, flags, centers (x,y), hand types and the
+    params_dict split all equal what the reference's ResultParser.parse returned for the same maps."""
+    g = golden('decode_cases.npz')
+    maps = {k: torch.from_numpy(v) for k, v in cases.decode_maps(name).items()}
+    meta = {'batch_ids': torch.arange(1), 'offsets': torch.zeros(1, 10), 'imgpath': ['a']}
+    out = pkg('acr.result_parser').rows_from_slots(_slots_tensor(odec.decode(maps)), meta)
+    np.testing.assert_array_equal(out['detection_flag'].numpy(), g[name + '_detection_flag'])
+    np.testing.assert_allclose(out['params_pred'].numpy(), g[name + '_params_pred'], 1e-6, 1e-6)
+    np.testing.assert_allclose(out['params_dict']['poses'].numpy(), g[name + '_poses'], 1e-5, 1e-5)
+    np.testing.assert_allclose(out['params_dict']['betas'].numpy(), g[name + '_betas'], 1e-6, 1e-6)
+    np.testing.assert_allclose(out['params_dict']['cam'].numpy(), g[name + '_cam'], 1e-6, 1e-6)
+    np.testing.assert_array_equal(out['l_centers_pred'].numpy(), g[name + '_l_centers_pred'])
+    np.testing.assert_array_equal(out['r_centers_pred'].numpy(), g[name + '_r_centers_pred'])
+    np.testing.assert_array_equal(out['output_hand_type'].numpy(), g[name + '_hand_type'])
+    assert out['output_hand_type'].dtype == torch.int32
+    assert int(out['left_hand_num']) == 1 and int(out['right_hand_num']) == 1
+    assert out['reorganize_idx'].tolist() == [0, 0] and meta['offsets'].shape == (2, 10)
+
+
+def test_rows_from_slots_batch_ordering():
+    names = ['both_near', 'left_only', 'none', 'right_only', 'both_far']
+    maps = {k: torch.cat([torch.from_numpy(cases.decode_maps(n)[k]) for n in names]) for k in cases.decode_maps(names[0])}
+    meta = {'batch_ids': torch.arange(10, 15)}
+    out = pkg('acr.result_parser').rows_from_slots(_slots_tensor(odec.decode(maps)), meta)
+    assert int(out['left_hand_num']) == 3 and int(out['right_hand_num']) == 3
+    assert out['reorganize_idx'].tolist() == [10, 11, 14, 10, 13, 14]      # left rows ascending, then right rows
+    assert out['output_hand_type'].tolist() == [0, 0, 0, 1, 1, 1]
+    assert out['detection_flag'].tolist() == [1.0] * 6
+
+
+def test_config_rejects_what_the_reference_rejects():
+    cfg = pkg('config')
+    ns = cfg.parse_args(['--configs_yml', '/nonexistent.yml'])
+    assert ns.centermap_conf_thresh == 0.35 and ns.align_idx == 9 and ns.kernel_sizes == [5]
+    for bad in (['--backbone', 'resnet'], ['--prior_mode', 'merge'], ['--Rot_type', 'aa'], ['--centermap_size', '32'],
+                ['--model_precision', 'fp16'], ['--attention_mode', 'none']):
+        with pytest.raises(ValueError):
+            cfg.parse_args(['--configs_yml', '/nonexistent.yml'] + bad)
+    assert cfg.parse_args(['--configs_yml', '/nonexistent.yml', '-t']).temporal_optimization is True
+
+
+def test_pack_conv_layout_and_bn_folding(synth_sd):
+    packer = pkg('packer')
+    w = np.arange(40 * 10 * 9, dtype=np.float32).reshape(40, 10, 3, 3)
+    wp, bp = packer.pack_conv(w, np.arange(40, dtype=np.float32))
+    assert wp.size == 9 * 2 * 2 * 64 * 4 and bp.size == 64           # cin8 = 2, n_tiles = 2
+    wp = wp.reshape(3, 3, 2, 2, 64, 4)
+    for (ky, kx, s, nt, lane, e) in [(0, 0, 0, 0, 0, 0), (2, 1, 1, 1, 37, 1), (1, 2, 0, 1, 7, 3), (1, 1, 1, 0, 63, 3)]:
+        co, ci = nt * 32 + (lane & 31), 8 * s + 4 * (lane >> 5) + e
+        want = w[co, ci, ky, kx] if (co < 40 and ci < 10) else 0.0
+        assert wp[ky, kx, s, nt, lane, e] == want
+    P = packer.Program(synth_sd)
+    wf, bf = P.folded('backbone.conv1', 'backbone.bn1')
+    x = torch.randn(1, 3, 8, 8, dtype=torch.float64)
+    ref = torch.nn.functional.batch_norm(
+        torch.nn.functional.conv2d(x, synth_sd['backbone.conv1.weight'].double(), None, 2, 1),
+        synth_sd['backbone.bn1.running_mean'].double(), synth_sd['backbone.bn1.running_var'].double(),
+        synth_sd['backbone.bn1.weight'].double(), synth_sd['backbone.bn1.bias'].double(), False, 0.0, 1e-5)
+    got = torch.nn.functional.conv2d(x, torch.from_numpy(wf), torch.from_numpy(bf), 2, 1)
+    assert (ref - got).abs().max() < 1e-12
+
+
+def test_lowering_accounts_for_every_flop_and_rejects_bad_checkpoints(synth_sd):
+    packer = pkg('packer')
+    prog = packer.lower({'module.' + k: v for k, v in synth_sd.items()})       # wild.pkl style prefix
+    assert abs(sum(o['flops'] for o in prog['op_info']) / 1e9 - 102.1) < 0.1
+    assert len(prog['ops']) < 400 and prog['blob'].dtype == np.float32
+    bad = dict(synth_sd)
+    del bad['backbone.stage3.1.branches.2.3.bn2.running_var']
+    with pytest.raises(ValueError):
+        packer.lower(bad)
+    bad = dict(synth_sd)
+    bad['contact_layers.4.weight'] = torch.zeros(109, 100, 1, 1)
+    with pytest.raises(ValueError):
+        packer.lower(bad)
+
+
+def test_img_preprocess_offsets_and_identity_resize():
+    u = pkg('acr.utils')
+    bgr = np.random.RandomState(0).randint(0, 256, (512, 512, 3), dtype=np.uint8)
+    d = u.img_preprocess(bgr, 'x.jpg', single_img_input=True)
+    assert d['image'].dtype == torch.uint8 and tuple(d['image'].shape) == (1, 512, 512, 3)
+    assert np.array_equal(d['image'][0].numpy(), bgr[:, :, ::-1])               # BGR->RGB, 512->512 is exact
+    assert d['offsets'][0].tolist() == [512, 512, 0, 0, 0, 0, 0, 0, 0, 0]
+    wide = np.zeros((1080, 1920, 3), np.uint8)
+    d = u.img_preprocess(wide, None, single_img_input=True)
+    assert d['offsets'][0].tolist() == [1920, 1920, 0, 0, 0, 0, 420, 0, 420, 0]
+    assert (d['image'][0, :100] == 255).all() and (d['image'][0, 200:300] == 0).all()   # white pad, black frame
+
+
+def test_one_euro_filter_and_smoothing():
+    u = pkg('acr.utils')
+    f = u.create_OneEuroFilter(4.0)
+    pose = torch.randn(48) * 0.3
+    p1, b1 = u.smooth_results(f, pose.clone(), torch.zeros(10))
+    assert torch.allclose(p1, pose, atol=1e-5)                                  # first sample passes through
+    p2, _ = u.smooth_results(f, pose + 0.5, torch.zeros(10))
+    assert ((p2[3:] - pose[3:]) > 0).all() and ((p2[3:] - pose[3:]) < 0.5).all()    # low-pass between samples
+
+
+def test_estimate_translation_matches_reference_fallback():
+    g = golden('e2e_batch1.npz')
+    u = pkg('acr.utils')
+    t = u.estimate_translation(torch.from_numpy(g['f0_j3d']), torch.from_numpy(g['f0_pj2d']), focal_length=1265)
+    np.testing.assert_allclose(t.numpy(), g['f0_cam_trans'], rtol=2e-3, atol=2e-3)
+
+
+def test_state_dict_surface_without_gpu(synth_sd):
+    """acr.model.ACR keeps the reference's key names; load_state_dict accepts 'module.'-prefixed checkpoints."""
+    m = pkg('acr.model').ACR()
+    assert list(m.state_dict().keys()) == list(pkg('schema').state_dict_schema().keys())
+    missing, unexpected = m.load_state_dict({'module.' + k: v for k, v in synth_sd.items()})
+    assert missing == [] and unexpected == []
+    assert torch.equal(m.state_dict()['l_final_layers.2.2.bias'], synth_sd['l_final_layers.2.2.bias'])
+    with pytest.raises(ValueError):
+        m.load_state_dict({'backbone.conv1.weight': torch.zeros(3, 3)})

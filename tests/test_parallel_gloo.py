@@ -1,0 +1,112 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the frame-sharding + single all-gather path
+(parallel.py).  The per-rank compute is the CPU oracle standing in for Engine.forward; what is under test
+is sharding, the packed result buffer, the collective and the global frame order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from conftest import PKG, ROOT, pkg
+
+NAMES = ['both_near', 'left_only', 'right_only', 'both_far', 'none', 'edge_corner']
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_forward(tables):
+    from oracle import decode as odec, mano as omano
+    L = pkg('_lib')
+
+    def fwd(frames, views):
+        ids = [int(f[0, 0, 0]) for f in frames]
+        maps = {k: torch.cat([torch.from_numpy(cases.decode_maps(NAMES[i])[k]) for i in ids])
+                for k in cases.decode_maps(NAMES[0])}
+        s = odec.decode(maps)
+        sl = views['slots']
+        sl.zero_()
+        sl[:, :, L.SLOT_FLAG] = torch.from_numpy(s['flag'].astype(np.float32))
+        sl[:, :, L.SLOT_FLATIND] = torch.from_numpy(s['flat_ind'].astype(np.float32))
+        sl[:, :, L.SLOT_POSES:L.SLOT_POSES + 48] = torch.from_numpy(s['poses'])
+        sl[:, :, L.SLOT_BETAS:L.SLOT_BETAS + 10] = torch.from_numpy(s['betas'])
+        sl[:, :, L.SLOT_PARAMS:L.SLOT_PARAMS + 109] = torch.from_numpy(s['params_pred'])
+        for h, name in ((0, 'left'), (1, 'right')):
+            v, j, _ = omano.mano_forward(tables[name], name, s['poses'][:, h], s['betas'][:, h])
+            views['verts'][:, h] = torch.from_numpy(v)
+            views['joints'][:, h] = torch.from_numpy(j)
+    return fwd
+
+
+def _frames(n):
+    f = torch.zeros(n, 4, 4, 3, dtype=torch.uint8)
+    for i in range(n):
+        f[i, 0, 0, 0] = i
+    return f
+
+
+def _worker(rank, world, port, q):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'tests', 'golden'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import importlib
+        parallel = importlib.import_module(PKG + '.parallel')
+        synth = importlib.import_module(PKG + '.synth')
+        tables = synth.make_mano_tables(seed=1)
+        runner = parallel.ShardedRunner(_oracle_forward(tables), torch.device('cpu'))
+        frames = _frames(len(NAMES))
+        got = runner.forward_global(frames)               # strong-scaling entry: shard of the global batch
+        lo, hi = parallel.shard_range(len(NAMES), rank, world)
+        got2 = runner.forward_local(frames[lo:hi])         # weak-scaling entry gives the same thing
+        q.put((rank, {k: v.numpy() for k, v in got.items()}, all(torch.equal(got[k], got2[k]) for k in got)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_forward_equals_single_process(mano_tables):
+    parallel = pkg('parallel')
+    flat, views = parallel.alloc_result(len(NAMES), torch.device('cpu'))
+    _oracle_forward(mano_tables)(_frames(len(NAMES)), views)
+    want = {k: v.numpy().copy() for k, v in views.items()}
+
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, same in res:
+        assert same
+        for k in ('slots', 'verts', 'joints'):
+            assert got[k].shape == want[k].shape
+            np.testing.assert_array_equal(got[k], want[k])     # every rank holds the full, ordered result
+
+
+def test_shard_range_and_buffer_layout():
+    parallel = pkg('parallel')
+    assert parallel.shard_range(512, 3, 8) == (192, 256)
+    with pytest.raises(ValueError):
+        parallel.shard_range(10, 0, 4)
+    flat, v = parallel.alloc_result(3, torch.device('cpu'))
+    assert flat.numel() == 3 * 2 * parallel.PER_HAND == 3 * 2 * (176 + 778 * 3 + 21 * 3)
+    assert v['slots'].shape == (3, 2, 176) and v['verts'].shape == (3, 2, 778, 3) and v['joints'].shape == (3, 2, 21, 3)
+    v['joints'].fill_(7.0)
+    assert flat[-1] == 7.0 and v['verts'].is_contiguous()
