@@ -32,7 +32,7 @@ def pkg(sub):
     return importlib.import_module(PKG + '.' + sub)
 
 
-def cpu_baseline(sd, tables, n_frames=2):
+def cpu_baseline(sd, tables, n_frames=8):
     """The oracle (CPU restatement of the reference, oracle/) timed on this box's host cores."""
     from oracle import acr_net, decode as odec, mano as omano
     frames = torch.from_numpy(pkg('synth').make_frames(n_frames, seed=3))
