@@ -432,6 +432,25 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
 
 int acrmi_tune(int key, int value) {
   if (key == 0) { conv_force_cfg(value); return ACRMI_OK; }
+  if (key == 3) { conv_set_phase_delay(value); return ACRMI_OK; }
+  static long long* dbg = nullptr;
+  if (key == 1) {   // enable (value != 0) / disable the conv kernel's cycle stamps (workgroup 0, wave 0)
+    if (value && !dbg) { if (hipMalloc(&dbg, 64 * sizeof(long long)) != hipSuccess) return ACRMI_EHIP; }
+    if (dbg) (void)hipMemset(dbg, 0, 64 * sizeof(long long));
+    conv_set_debug(value ? dbg : nullptr);
+    return ACRMI_OK;
+  }
+  if (key == 2) {   // print the stamps of the last conv launch as deltas (device is synchronised first)
+    if (!dbg) return ACRMI_OK;
+    long long h[64];
+    if (hipDeviceSynchronize() != hipSuccess) return ACRMI_EHIP;
+    if (hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return ACRMI_EHIP;
+    const int n = (int)h[63];
+    printf("conv stamps (%d):", n);
+    for (int i = 1; i < n && i < 60; ++i) printf(" %lld", h[i] - h[i - 1]);
+    printf("\n");
+    return ACRMI_OK;
+  }
   return fail(nullptr, ACRMI_EINVAL, "acrmi_tune: unknown key %d", key);
 }
 

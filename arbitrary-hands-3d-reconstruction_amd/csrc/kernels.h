@@ -19,12 +19,16 @@ struct ConvArgs {
   int n_tiles;          // 32-cout tiles per group in the packed weights (CoutP/32)
   int cin8;             // ceil(Cin/8)
   int bias_fstride;     // floats between frames' bias rows (0 = shared)
+  long long* dbg;       // optional device buffer for cycle stamps (tuning only)
+  int phase_delay;      // tuning: cycles the second half of the grid sleeps before starting (0 = off)
 };
 
 // returns hipSuccess or the launch error; cout tiles etc. derived inside
 hipError_t launch_conv(ConvArgs a, hipStream_t s);
 const char* conv_kernel_name(const ConvArgs& a);
 void conv_force_cfg(int cfg);
+void conv_set_debug(long long* dbg);
+void conv_set_phase_delay(int cycles);
 
 hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStream_t s);
 hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,

@@ -43,11 +43,14 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--filter', default='')
+    ap.add_argument('--phase', type=int, default=0, help='cycles the second half of the grid sleeps first')
+    ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
     args = ap.parse_args()
     L = importlib.import_module(PKG + '._lib')
     packer = importlib.import_module(PKG + '.packer')
     lib = L.lib()
     lib.acrmi_tune(0, args.cfg)
+    lib.acrmi_tune(3, args.phase)
     B = args.batch
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     for name, cin, cout, H, W, k, stride, groups, use_res in SHAPES:
@@ -81,6 +84,11 @@ def main():
         flops = 2.0 * B * Ho * Wo * coutg * cing * k * k * groups
         byts = 4.0 * B * (H * W * cin + Ho * Wo * cout * (2 if use_res else 1))
         print('%-28s %8.3f ms  %6.1f TF  %6.2f TB/s(min traffic)' % (name, ms, flops / ms / 1e9, byts / ms / 1e9), flush=True)
+        if args.stamps:
+            lib.acrmi_tune(1, 1)
+            launch()
+            lib.acrmi_tune(2, 0)
+            lib.acrmi_tune(1, 0)
 
 
 if __name__ == '__main__':
