@@ -74,7 +74,7 @@ def lib():
                              f32p, vp]
     L.acrmi_forward.argtypes = [vp, u8p, i32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp]
     L.acrmi_conv2d.argtypes = [f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, i32, f32p, i32, i32, f32p, i32, i32,
-                               i32, i32, i32, i32, i32, vp]
+                               i32, i32, i32, i32, i32, i32, vp]
     L.acrmi_u8norm.argtypes = [u8p, i32, f32p, vp]
     L.acrmi_bilinear2x.argtypes = [f32p, i32, i32, i32, i32, i32, f32p, i32, vp]
     L.acrmi_fuse_sum.argtypes = [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, f32p, i32,

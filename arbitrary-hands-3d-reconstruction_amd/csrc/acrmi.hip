@@ -124,6 +124,7 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       a.cin8 = (op.cin + 7) / 8;
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
+      a.algo = op.flags & 1;
       HIPCHK(c, launch_conv(a, s));
       return ACRMI_OK;
     }
@@ -374,9 +375,12 @@ int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets,
 // ---- stand-alone operators -------------------------------------------------------------------------
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff, float* out,
-                 int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups, void* stream) {
+                 int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups, int algo,
+                 void* stream) {
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0)
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
+  if (algo != 0 && !(algo == 1 && ksize == 3 && stride == 1))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-1 convolution", algo);
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))
@@ -393,6 +397,7 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   a.cin8 = (cin + 7) / 8;
   a.n_tiles = cout <= 32 ? 1 : ((cout + 63) / 64) * 2;
   a.bias_fstride = bias_frame_stride;
+  a.algo = algo;
   hipError_t e = launch_conv(a, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
   return ACRMI_OK;

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .packer import pack_conv, n_tiles_for
+from .packer import pack_conv, n_tiles_for, winograd_weights
 
 
 def _p(t):
@@ -33,7 +33,7 @@ def to_nhwc(x_nchw, cs=None, device='cuda'):
 
 
 def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, cin=None, in_coff=0, out=None,
-           out_coff=0, out_cs=None, frame_bias=None):
+           out_coff=0, out_cs=None, frame_bias=None, algo='direct'):
     """x: NHWC [B,H,W,cs] device fp32; weight: [Cout_total, Cin/groups, k, k] (torch/numpy, host or device);
     padding = k//2 (the only padding the ACR network uses).  Returns NHWC [B,Ho,Wo,out_cs]."""
     _need_cuda(x, residual, out, frame_bias)
@@ -42,7 +42,16 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     cout = cout_t // groups
     b = np.zeros(cout_t, np.float32) if bias is None else (
         bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
-    packed = [pack_conv(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout]) for g in range(groups)]
+    if algo == 'winograd':
+        if k != 3 or stride != 1:
+            raise ValueError('winograd needs a 3x3 stride-1 convolution')
+        tr = winograd_weights
+    elif algo == 'direct':
+        tr = lambda t: t
+    else:
+        raise ValueError('algo must be "direct" or "winograd"')
+    packed = [pack_conv(tr(w[g * cout:(g + 1) * cout].astype(np.float64)), b[g * cout:(g + 1) * cout])
+              for g in range(groups)]
     wp = torch.from_numpy(np.concatenate([p[0] for p in packed])).to(x.device)
     bp = torch.from_numpy(np.concatenate([p[1] for p in packed])).to(x.device)
     B, H, W, cs = x.shape
@@ -58,7 +67,7 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     L = _lib.lib()
     _lib.check(L.acrmi_conv2d(_p(x), B, H, W, cs, in_coff, cin, _p(wp), _p(bias_t), fstride, _p(residual),
                               residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1], out_coff,
-                              cout, k, stride, int(relu), groups, _s(x)))
+                              cout, k, stride, int(relu), groups, 1 if algo == 'winograd' else 0, _s(x)))
     return out
 
 

@@ -13,6 +13,9 @@ from . import _lib
 from .schema import STAGE_CFG, state_dict_schema
 
 EPS = 1e-5
+# 3x3 stride-1 convolutions run as Winograd F(2,3) along x (exact-arithmetic equivalent, 1.5x fewer MFMAs;
+# fp32 round-off differs from the direct form by ~1e-6 relative).  Set False to lower everything to direct conv.
+WINOGRAD = True
 
 
 def _np(t):
@@ -52,16 +55,30 @@ def pack_conv(w, b):
     """w [Cout,Cin,k,k], b [Cout] (float64/32) -> (packed weights fp32 1-D, padded bias fp32 [n_tiles*32]).
     Packed index: [tap][s = ci/8][ntile][lane 64][e 4] with cout = ntile*32 + (lane & 31),
     ci = 8*s + 4*(lane >> 5) + e."""
-    cout, cin, k, _ = w.shape
+    cout, cin, kh, kw = w.shape
     nt = n_tiles_for(cout)
     c8 = (cin + 7) // 8
-    wp = np.zeros((nt * 32, c8 * 8, k, k), np.float32)
+    wp = np.zeros((nt * 32, c8 * 8, kh, kw), np.float32)
     wp[:cout, :cin] = w
-    wp = wp.reshape(nt, 32, c8, 2, 4, k, k)             # [nt, j, s, h, e, ky, kx]
+    wp = wp.reshape(nt, 32, c8, 2, 4, kh, kw)           # [nt, j, s, h, e, ky, kx]
     wp = wp.transpose(5, 6, 2, 0, 3, 1, 4)               # [ky, kx, s, nt, h, j, e]
     bp = np.zeros(nt * 32, np.float32)
     bp[:cout] = b
     return np.ascontiguousarray(wp).reshape(-1), bp
+
+
+WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def winograd_weights(w):
+    """[Cout,Cin,3,3] -> [Cout,Cin,3,4]: Winograd F(2,3) weight transform along kx, U[ky][v] = sum_kx G[v][kx] w[ky][kx]
+    (fp64 in, rounded once by pack_conv).  conv_wino_kernel consumes them as 3x4 'taps'."""
+    assert w.shape[2:] == (3, 3)
+    return np.einsum('vk,oiyk->oiyv', WINO_G, np.asarray(w, np.float64))
+
+
+def use_winograd(k, stride):
+    return k == 3 and stride == 1
 
 
 class Blob(object):
@@ -145,14 +162,16 @@ class Program(object):
         ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w_ + 2 * (k // 2) - k) // stride + 1
         if out is None:
             out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
-        packed = [pack_conv(w, b) for (w, b) in wb_list]
+        wino = WINOGRAD and use_winograd(k, stride)
+        packed = [pack_conv(winograd_weights(w) if wino else w, b) for (w, b) in wb_list]
         w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
-        flops = 2.0 * ho * wo * cout * cin_w * k * k * len(wb_list)
+        flops = 2.0 * ho * wo * cout * cin_w * k * k * len(wb_list)     # algorithmic (direct-conv) FLOPs
         self._op(name, flops, kind=_lib.OP_CONV, in_buf=src, out_buf=out, res_buf=-1 if res is None else res,
                  in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
-                 relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off,
+                 relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=1 if wino else 0,
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
+        self.op_info[-1]['algo'] = 'winograd_f23x' if wino else 'direct'
         return out
 
     def conv_bn(self, src, conv, bn, k, stride, relu, **kw):

@@ -154,11 +154,12 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
                   float* pj2d_org_dev, void* stream);
 
 /* Stand-alone operators (same kernels the program uses; for parity tests and embedding).
- * w_packed/bias come from the Python packer (pack_conv). */
+ * w_packed/bias come from the Python packer (pack_conv).  algo: 0 = direct convolution;
+ * 1 = Winograd F(2,3) along x (3x3 stride 1 only; w_packed = pack_conv(winograd_weights(w))). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,
-                 void* stream);
+                 int algo, void* stream);
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
 int acrmi_bilinear2x(const float* in, int B, int H, int W, int in_cs, int C, float* out, int out_cs, void* stream);
 int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, const int* term_shift, int B, int H,

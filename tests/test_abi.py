@@ -56,4 +56,4 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert lib.acrmi_create(None, 0) == L.E_INVAL
     assert lib.acrmi_load_weights(None, None, 0) == L.E_INVAL
     assert lib.acrmi_decode(None, 1, None, None) == L.E_INVAL
-    assert lib.acrmi_conv2d(None, 1, 8, 8, 8, 0, 8, None, None, 0, None, 0, 0, None, 8, 0, 8, 3, 1, 0, 1, None) == L.E_INVAL
+    assert lib.acrmi_conv2d(None, 1, 8, 8, 8, 0, 8, None, None, 0, None, 0, 0, None, 8, 0, 8, 3, 1, 0, 1, 0, None) == L.E_INVAL

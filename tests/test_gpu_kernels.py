@@ -69,6 +69,36 @@ def test_conv2d_matches_torch(ops, case):
         assert out[..., cout:].abs().max().item() == 0.0     # pad channels untouched
 
 
+WINO_CASES = [c for c in CONV_CASES if c[5] == 3 and c[6] == 1] + [
+    (1, 32, 32, 16, 18, 3, 1, 1, False, True),       # Wo not a multiple of the tile, even
+    (1, 8, 40, 7, 9, 3, 1, 1, True, False),          # odd width: the last pair has one valid pixel
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: 'wino_B%d_%dto%d_%dx%d_g%d' % (c[0], c[1], c[2], c[3], c[4], c[7]))
+def test_conv2d_winograd_matches_torch(ops, case):
+    """3x3 stride-1 convolutions through the Winograd F(2,3)-along-x kernel vs an fp64 direct convolution."""
+    B, cin, cout, H, W, k, stride, groups, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 1)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, k, k, generator=g) / np.sqrt(cin // groups * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1, 1, groups)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv2d(ops.to_nhwc(x), w, b, relu=relu, groups=groups, cin=cin // groups, algo='winograd',
+                     residual=None if res is None else ops.to_nhwc(res))
+    torch.cuda.synchronize()
+    err = (_nchw(out, cout).double() - ref).abs().max().item()
+    assert err < 3e-5, err          # Winograd F(2,3) in fp32: ~2x the direct kernel's round-off
+    if out.shape[-1] > cout:
+        assert out[..., cout:].abs().max().item() == 0.0
+
+
 def test_conv2d_channel_slices_and_frame_bias(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 109, 16, 16, generator=g)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--filter', default='')
+    ap.add_argument('--wino', action='store_true', help='3x3 stride-1 shapes through the Winograd F(2,3) kernel')
     ap.add_argument('--phase', type=int, default=0, help='cycles the second half of the grid sleeps first')
     ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
     args = ap.parse_args()
@@ -63,13 +64,15 @@ def main():
         out = torch.empty(B, Ho, Wo, cs_out, device='cuda')
         res = torch.randn(B, Ho, Wo, cs_out, device='cuda') if use_res else None
         w = (np.random.randn(coutg, cing, k, k) / np.sqrt(cing * k * k)).astype(np.float32)
-        packed = [packer.pack_conv(w, np.zeros(coutg, np.float32)) for _ in range(groups)]
+        wino = 1 if (args.wino and k == 3 and stride == 1) else 0
+        packed = [packer.pack_conv(packer.winograd_weights(w) if wino else w, np.zeros(coutg, np.float32))
+                  for _ in range(groups)]
         wp = torch.from_numpy(np.concatenate([q[0] for q in packed])).cuda()
         bp = torch.from_numpy(np.concatenate([q[1] for q in packed])).cuda()
 
         def launch():
             rc = lib.acrmi_conv2d(p(x), B, H, W, cs_in, 0, cing, p(wp), p(bp), 0, p(res), cs_out, 0, p(out), cs_out, 0,
-                                  coutg, k, stride, 1, groups, None)
+                                  coutg, k, stride, 1, groups, wino, None)
             assert rc == 0, lib.acrmi_last_error(None)
         for _ in range(3):
             launch()
