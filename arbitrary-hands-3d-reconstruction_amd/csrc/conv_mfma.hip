@@ -64,7 +64,7 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   const int c4off = (ltid % (CK / 4)) * 4;
   for (int k = 0; k < ktotal; ++k) {
     if (c0 == 0) {
-      const int tile = w % wk.n_tiles_total;
+      const int tile = (w / wk.nblk) % wk.n_tiles_total;
       const int g = (w / wk.n_tiles_total) / wk.nblk;
       const int b = tile / wk.tiles_per_frame;
       const int t = tile - b * wk.tiles_per_frame;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void epi_store_vec(const EpiCtx& e, Slot2Pix slot2pix
     }
     bool ok;
     const int pix = slot2pix(slot_base + 8 * gq + 4 * lh + lj, ok);
-    if (ok) *reinterpret_cast<f32x4*>(e.outb + pix * e.out_cs + co0 + 4 * lq) = v;
+    if (ok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(e.outb + pix * e.out_cs + co0 + 4 * lq));
   }
 }
 
@@ -255,9 +255,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_ws_ker
   if (stamp) a.dbg[ns_++] = clock64();
   for (int k = 0; k < ktotal; ++k) {
     const float* patch = lds + (k & 1) * BUF;
-    const int rest = w / wk.n_tiles_total;
-    const int g = rest / wk.nblk;
-    const int n_tile0 = ((rest % wk.nblk) * WAVES_N + wn) * NTW;
+    // item order: N-block fastest, then tile, then group - the N-blocks of one tile run at the same time on
+    // neighbouring workgroups, so the tile's input patch is fetched from HBM once and re-read from MALL/L2
+    const int rest = w % wk.nblk;
+    const int g = w / (wk.nblk * wk.n_tiles_total);
+    const int n_tile0 = (rest * WAVES_N + wn) * NTW;
     const bool wave_active = n_tile0 < a.n_tiles;
     const bool last_chunk = c0 + CK >= cin_pad;
     if (wave_active) {
@@ -306,7 +308,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_ws_ker
     __syncthreads();
     if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
     if (wave_active && last_chunk) {
-      const int tile = w % wk.n_tiles_total;
+      const int tile = (w / wk.nblk) % wk.n_tiles_total;
       const int b = tile / wk.tiles_per_frame;
       const int t = tile - b * wk.tiles_per_frame;
       const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
@@ -394,9 +396,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
   __syncthreads();   // barrier 0
   for (int k = 0; k < ktotal; ++k) {
     const float* patch = lds + (k & 1) * BUF;
-    const int rest = w / wk.n_tiles_total;
-    const int g = rest / wk.nblk;
-    const int n_tile = (rest % wk.nblk) * WAVES_N + wn;
+    // item order: N-block fastest, then tile, then group - the N-blocks of one tile run at the same time on
+    // neighbouring workgroups, so the tile's input patch is fetched from HBM once and re-read from MALL/L2
+    const int rest = w % wk.nblk;
+    const int g = w / (wk.nblk * wk.n_tiles_total);
+    const int n_tile = rest * WAVES_N + wn;
     const bool wave_active = n_tile < a.n_tiles;
     const bool last_chunk = c0 + CK >= cin_pad;
     if (wave_active) {
@@ -439,7 +443,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
     }
     __syncthreads();
     if (wave_active && last_chunk) {
-      const int tile = w % wk.n_tiles_total;
+      const int tile = (w / wk.nblk) % wk.n_tiles_total;
       const int b = tile / wk.tiles_per_frame;
       const int t = tile - b * wk.tiles_per_frame;
       const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
@@ -601,6 +605,9 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   }
   if (a.ks == 1 && a.stride == 1) {
     if (n32) return small ? launch_ws<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s) : launch_ws<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
+    if (g_force_cfg == 401) return launch_ws<1, 1, 16, 16, 4, 2, 1, 2, 32, 2>(a, s);
+    if (g_force_cfg == 402) return launch_ws<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s);
+    if (g_force_cfg == 403) return launch_ws<1, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s);
     return small ? launch_ws<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s) : launch_ws<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
   }
   return hipErrorInvalidValue;
