@@ -361,7 +361,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_ws_ker
 // each compute wave owns 32 pairs x 32 couts with 4 position accumulators (64 registers).
 // "taps" of the packed weights = 3 (ky) x 4 (positions): U[ky][v] = sum_kx G[v][kx] w[ky][kx].
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW>
+template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_kernel(const ConvArgs a, const ConvWork wk) {
   constexpr int PH = TH + 2, PW = TW + 2, CP = CK + 4;
   constexpr int NCW = WAVES_M * WAVES_N;
@@ -393,7 +393,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
   const size_t step_stride = (size_t)a.n_tiles * 256;
 
   int w = blockIdx.x, c0 = 0;
+  const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
+  int ns_ = 0;
+  if (stamp) a.dbg[ns_++] = clock64();
   __syncthreads();   // barrier 0
+  if (stamp) a.dbg[ns_++] = clock64();
   for (int k = 0; k < ktotal; ++k) {
     const float* patch = lds + (k & 1) * BUF;
     // item order: N-block fastest, then tile, then group - the N-blocks of one tile run at the same time on
@@ -407,41 +411,60 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
       const int nsteps = (cin_pad - c0 < CK ? cin_pad - c0 : CK) / 8;
       const float* __restrict__ wchunk = a.w + (size_t)g * 12 * tap_stride + (size_t)n_tile * 256 + lane * 4 +
                                          (size_t)(c0 / 8) * step_stride;
-      f32x4 d[2][4], bv[2][4];
+      // Row groups g = (s, ky): three statically indexed fragment buffers (index = ky), LDS windows fetched one
+      // group ahead, weight fragments two groups ahead; no register copies (the buffer of group g+2 is the one
+      // group g-1 used).  All weight offsets are 32-bit: 12 loop-invariant (ky, position) offsets plus one
+      // per-step offset, so a fragment address costs an s_add instead of a 64-bit multiply chain (the scalar
+      // address arithmetic between MFMAs otherwise leaves bubbles in the matrix pipe).
+      const int tap_i = (int)tap_stride, step_i = (int)step_stride;
+      f32x4 d[3][4], bv[3][4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         d[0][c] = *reinterpret_cast<const f32x4*>(patch + aoff + c * CP);
-        bv[0][c] = *reinterpret_cast<const f32x4*>(wchunk + (size_t)c * tap_stride);
+        bv[0][c] = *reinterpret_cast<const f32x4*>(wchunk + c * tap_i);
+        bv[1][c] = *reinterpret_cast<const f32x4*>(wchunk + (4 + c) * tap_i);
       }
       for (int s = 0; s < nsteps; ++s) {
+        const int sn = s + 1 < nsteps ? s + 1 : s;      // next step (the tail re-reads a valid one)
+        const int sb = s * step_i, snb = sn * step_i;   // weight offsets of this / the next step
+        const int s8 = s * 8, sn8 = sn * 8;             // LDS channel offsets
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const int cur = ky & 1, nxt = cur ^ 1;
-          const int nky = ky + 1 < 3 ? ky + 1 : 0;
-          const int ns = ky + 1 < 3 ? s : (s + 1 < nsteps ? s + 1 : s);
+          {   // LDS window of the next group -> d[(ky+1)%3]
+            const int k1 = ky == 2 ? 0 : ky + 1;
+            const int so = ky == 2 ? sn8 : s8;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            d[nxt][c] = *reinterpret_cast<const f32x4*>(patch + aoff + (nky * PW + c) * CP + ns * 8);
-            bv[nxt][c] = *reinterpret_cast<const f32x4*>(wchunk + (size_t)(nky * 4 + c) * tap_stride + (size_t)ns * step_stride);
+            for (int c = 0; c < 4; ++c)
+              if (ABL != 2) d[(ky + 1) % 3][c] = *reinterpret_cast<const f32x4*>(patch + aoff + (k1 * PW + c) * CP + so);
+          }
+          {   // weight fragments two groups ahead -> bv[(ky+2)%3]
+            const int k2 = (ky + 2) % 3;
+            const int wo = ky == 0 ? sb : snb;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (ABL != 1) bv[(ky + 2) % 3][c] = *reinterpret_cast<const f32x4*>(wchunk + (k2 * 4 + c) * tap_i + wo);
           }
           __builtin_amdgcn_sched_barrier(0);
           f32x4 v[4];
-          v[0] = d[cur][0] - d[cur][2];
-          v[1] = d[cur][1] + d[cur][2];
-          v[2] = d[cur][2] - d[cur][1];
-          v[3] = d[cur][1] - d[cur][3];
+          if (ABL == 3) {
+            v[0] = d[ky][0]; v[1] = d[ky][1]; v[2] = d[ky][2]; v[3] = d[ky][3];
+          } else {
+            v[0] = d[ky][0] - d[ky][2];
+            v[1] = d[ky][1] + d[ky][2];
+            v[2] = d[ky][2] - d[ky][1];
+            v[3] = d[ky][1] - d[ky][3];
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-              acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][j], bv[cur][p][j], acc[p], 0, 0, 0);
+              acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][j], bv[ky][p][j], acc[p], 0, 0, 0);
         }
-        // 3 row groups per step: the double-buffer parity flips every s; re-align
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { d[0][c] = d[1][c]; bv[0][c] = bv[1][c]; }
       }
     }
+    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
     __syncthreads();
+    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
     if (wave_active && last_chunk) {
       const int tile = (w / wk.nblk) % wk.n_tiles_total;
       const int b = tile / wk.tiles_per_frame;
@@ -493,9 +516,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
     }
+    if (stamp && last_chunk && ns_ < 60) a.dbg[ns_++] = clock64();
     c0 += CK;
     if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
   }
+  if (stamp) a.dbg[63] = ns_;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,18 +538,12 @@ static hipError_t ensure_device_info() {
   return hipSuccess;
 }
 
-// k persistent workgroups per CU (k = 2 only if two double-buffers fit the LDS), minimising the busiest
-// CU's item count; ties go to the larger k (more waves to hide fragment latency)
+// One persistent workgroup per CU.  (Two per CU were measured: the 384-thread workgroups do not become
+// co-resident on gfx950 even when LDS and registers would allow it - the second half of the grid simply runs
+// after the first - so k = 2 only adds a second prologue/tail; PMC: profiles/r01_pmc_wino_b2.txt.)
 static long pick_grid(long total, size_t lds_bytes) {
-  const int max_k = lds_bytes <= 78 * 1024 ? 2 : 1;
-  int best_k = 1;
-  long best_cost = -1;
-  for (int k = 1; k <= max_k; ++k) {
-    const long slots = (long)g_num_cus * k;
-    const long cost = ((total + slots - 1) / slots) * k;
-    if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_k = k; }
-  }
-  long grid = (long)g_num_cus * best_k;
+  (void)lds_bytes;
+  const long grid = g_num_cus;
   return grid > total ? total : grid;
 }
 
@@ -553,12 +572,12 @@ static hipError_t launch_ws(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW>
+template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(TH + 2) * (TW + 2) * (CK + 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "two patch buffers must fit the 160 KiB LDS");
   constexpr int NTHREADS = (WAVES_M * WAVES_N + NLW) * 64;
-  auto kern = conv_wino_kernel<TH, TW, WAVES_M, WAVES_N, CK, NLW>;
+  auto kern = conv_wino_kernel<TH, TW, WAVES_M, WAVES_N, CK, NLW, ABL>;
   static bool init = false;
   if (!init) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -591,6 +610,9 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     // with 4x2 waves (register-limited to 168 VGPRs, spills) on every N>=64 layer: 113-133 vs 93-110 TF-eq
     if (g_force_cfg == 302) return launch_wino<16, 16, 4, 2, 32, 2>(a, s);
     if (g_force_cfg == 303) return launch_wino<16, 16, 4, 1, 32, 2>(a, s);
+    if (g_force_cfg == 601) return launch_wino<8, 16, 2, 2, 32, 2, 1>(a, s);   // timing ablations (wrong results)
+    if (g_force_cfg == 602) return launch_wino<8, 16, 2, 2, 32, 2, 2>(a, s);
+    if (g_force_cfg == 603) return launch_wino<8, 16, 2, 2, 32, 2, 3>(a, s);
     return launch_wino<8, 16, 2, 2, 32, 2>(a, s);
   }
   if (a.ks == 3 && a.stride == 1) {
