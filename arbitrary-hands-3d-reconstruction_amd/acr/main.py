@@ -119,6 +119,18 @@ class ACR(object):
         return results
 
 
+def _forward_raw_batch(self, bgr_frames_dev, paths):
+    """BASELINE.json config 4: raw BGR uint8 frames [n,H,W,3] resident in HBM (e.g. 1080p video) -> per-image
+    results.  Pre-processing (white square pad + bicubic resize to 512) runs on the GPU (ops.preprocess),
+    then the fused path; `offsets` carry the pad geometry so pj2d_org lands in original-frame pixels."""
+    from .utils import img_preprocess_gpu
+    meta = img_preprocess_gpu(bgr_frames_dev, paths)
+    return self.forward_batch(meta['image'], paths, offsets=meta['offsets'])
+
+
+ACR.forward_raw_batch = _forward_raw_batch
+
+
 def main(argv=None):
     """python -m <package>.acr.main --demo_mode folder --inputs DIR : runs the path on .npy / image files it can
     read without cv2 (uint8 HxWx3 BGR arrays saved with numpy)."""

@@ -403,6 +403,26 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   return ACRMI_OK;
 }
 
+int acrmi_preprocess(const uint8_t* bgr_dev, int n, int H, int W, uint8_t* out_rgb_dev, float* offsets_host,
+                     void* stream) {
+  if (!bgr_dev || !out_rgb_dev || n <= 0 || H <= 0 || W <= 0)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_preprocess: bad arguments");
+  // imgaug compute_paddings_to_reach_aspect_ratio(shape, 1.0): pad the shorter side, extra pixel bottom/right
+  const int S = H > W ? H : W;
+  int top = 0, right = 0, bottom = 0, left = 0;
+  if (W < H) { const int d = H - W; right = (d + 1) / 2; left = d / 2; }
+  else if (H < W) { const int d = W - H; top = d / 2; bottom = (d + 1) / 2; }
+  if (offsets_host) {
+    for (int i = 0; i < n; ++i) {
+      float* o = offsets_host + (size_t)i * 10;
+      o[0] = (float)S; o[1] = (float)S; o[2] = o[3] = o[4] = o[5] = 0.f;
+      o[6] = (float)top; o[7] = (float)right; o[8] = (float)bottom; o[9] = (float)left;
+    }
+  }
+  hipError_t e = launch_preprocess(bgr_dev, n, H, W, S, top, left, 512, out_rgb_dev, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "preprocess: %s", hipGetErrorString(e));
+}
+
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream) {
   if (!img || !out || n_pixels <= 0) return fail(nullptr, ACRMI_EINVAL, "acrmi_u8norm: bad arguments");
   hipError_t e = launch_u8norm(img, n_pixels, out, (hipStream_t)stream);

@@ -41,6 +41,8 @@ struct FuseArgs {
   float* out;
 };
 hipError_t launch_fuse_sum(const FuseArgs& a, hipStream_t s);
+hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int pad_top, int pad_left, int out_size,
+                             uint8_t* out, hipStream_t s);
 hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s);
 hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, hipStream_t s);
 

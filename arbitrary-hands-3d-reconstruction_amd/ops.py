@@ -71,6 +71,20 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     return out
 
 
+def preprocess(bgr_frames):
+    """uint8 BGR device frames [n,H,W,3] (all the same size) -> (uint8 RGB [n,512,512,3] device, offsets [n,10] host).
+    The device counterpart of acr.utils.img_preprocess (reference acr/utils.py:1315-1337)."""
+    _need_cuda(bgr_frames)
+    if bgr_frames.dtype != torch.uint8 or bgr_frames.dim() != 4 or bgr_frames.shape[-1] != 3:
+        raise ValueError('frames must be uint8 [n,H,W,3] BGR')
+    n, H, W, _ = bgr_frames.shape
+    out = torch.empty(n, 512, 512, 3, dtype=torch.uint8, device=bgr_frames.device)
+    offsets = np.zeros((n, 10), np.float32)
+    _lib.check(_lib.lib().acrmi_preprocess(_p(bgr_frames.contiguous()), n, H, W, _p(out),
+                                           offsets.ctypes.data_as(C.c_void_p), _s(bgr_frames)))
+    return out, torch.from_numpy(offsets)
+
+
 def u8norm(img):
     _need_cuda(img)
     B, H, W, _ = img.shape

@@ -160,6 +160,12 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,
                  int algo, void* stream);
+/* acr/utils.py:1276-1337 (img_preprocess / image_pad_white_bg / cv2.resize INTER_CUBIC): n BGR uint8 frames
+ * [n,H,W,3] on the device -> RGB uint8 [n,512,512,3] (white pad to square, bicubic a=-0.75, half-pixel
+ * centres, replicate border).  offsets_host [n,10] (may be NULL) receives the reference's `offsets` rows
+ * (padded h, padded w, crop trbl = 0, pad trbl). */
+int acrmi_preprocess(const uint8_t* bgr_dev, int n, int H, int W, uint8_t* out_rgb_dev, float* offsets_host,
+                     void* stream);
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
 int acrmi_bilinear2x(const float* in, int B, int H, int W, int in_cs, int C, float* out, int out_cs, void* stream);
 int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, const int* term_shift, int B, int H,

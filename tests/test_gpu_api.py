@@ -95,3 +95,35 @@ def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
     sd = pkg('synth').make_state_dict(seed=0, center_bias=(-50.0, -50.0))
     acr2 = pkg('acr.main').ACR(state_dict=sd, mano_tables=mano_tables)
     assert acr2(np.ascontiguousarray(frames2[0][:, :, ::-1]), 'n.jpg') == {'n.jpg': {}}
+
+
+def test_gpu_preprocess_matches_host_preprocess():
+    """§8f-1: the HIP pre-processing kernel == acr.utils.img_preprocess (white pad + bicubic a=-0.75) on the same
+    frames; cv2 itself is not available here, so parity with OpenCV's fixed-point INTER_CUBIC stays unpinned."""
+    u, ops = pkg('acr.utils'), pkg('ops')
+    rs = np.random.RandomState(4)
+    for H, W in ((1080, 1920), (480, 640), (700, 300), (512, 512), (333, 333)):
+        base = rs.randint(0, 256, (H // 8 + 2, W // 8 + 2, 3)).astype(np.float32)
+        frame = np.kron(base, np.ones((8, 8, 1), np.float32))[:H, :W] + rs.randint(-9, 10, (H, W, 3))
+        frame = np.clip(frame, 0, 255).astype(np.uint8)
+        host = u.img_preprocess(frame, None, single_img_input=True)
+        dev_img, dev_off = ops.preprocess(torch.from_numpy(frame)[None].cuda())
+        diff = (dev_img.cpu().int() - host['image'].int()).abs()
+        assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 2e-3, (H, W, diff.max().item())
+        assert torch.equal(dev_off, host['offsets'])
+
+
+def test_raw_1080p_batch_end_to_end(synth_sd, mano_tables):
+    """BASELINE.json config 4 shape: 1080p BGR frames in HBM -> GPU pre-processing -> fused path -> per-image hands;
+    equals the one-frame-at-a-time host-preprocessed route."""
+    acr = pkg('acr.main').ACR(state_dict=synth_sd, mano_tables=mano_tables, max_batch=2)
+    rs = np.random.RandomState(7)
+    frames = np.clip(np.kron(rs.randint(0, 256, (2, 135, 240, 3)).astype(np.float32), np.ones((1, 8, 8, 1), np.float32)), 0, 255).astype(np.uint8)
+    batch = acr.forward_raw_batch(torch.from_numpy(frames).cuda(), ['v0', 'v1'])
+    for i, name in enumerate(('v0', 'v1')):
+        single = acr(frames[i], name)[name]
+        assert len(batch[name]) == len(single)
+        for hb, hs in zip(batch[name], single):
+            assert int(hb['hand_type']) == int(hs['hand_type'])
+            assert np.abs(hb['verts'].astype(np.float32) - hs['verts'].astype(np.float32)).max() < 5e-3
+            assert np.abs(hb['pj2d_org'].astype(np.float32) - hs['pj2d_org'].astype(np.float32)).max() < 4.0   # px of 1920
