@@ -22,6 +22,8 @@
 //                       fragments (v0=d0-d2, v1=d1+d2, v2=d2-d1, v3=d1-d3), weights pre-transformed on the
 //                       host (G g), output transform (y0=m0+m1+m2, y1=m1-m2-m3) in the epilogue.
 #include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace acrmi {
 
@@ -43,9 +45,15 @@ struct ConvWork {
 // ------------------------------------------------------------------------------------------------
 // loader waves: fill LDS buffer (k & 1) with the patch of chunk k, one workgroup barrier per chunk
 // ------------------------------------------------------------------------------------------------
-template <int KS, int S, int TH, int TW, int CK, int NLW>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int, int, bool) const {}
+};
+
+// hook(item, item_seq, is_last_chunk) runs on the loader waves after chunk k's patch is written to LDS and
+// before barrier k (used to pre-stage the item's residual tile next to its last chunk).
+template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook>
 __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk, float* lds, int ltid, int ktotal,
-                                          int cin_pad) {
+                                          int cin_pad, Hook hook = Hook()) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4, PAD = KS / 2;
   constexpr int NLT = NLW * 64;
   constexpr int NLOAD = PH * PW * (CK / 4);
@@ -62,6 +70,7 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   unsigned pixok = 0;
   const float* __restrict__ inb = a.in;
   const int c4off = (ltid % (CK / 4)) * 4;
+  const int nchunks_l = (cin_pad + CK - 1) / CK;
   for (int k = 0; k < ktotal; ++k) {
     if (c0 == 0) {
       const int tile = (w / wk.nblk) % wk.n_tiles_total;
@@ -105,6 +114,7 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       if (!cok || !((pixok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (idx < NLOAD) *reinterpret_cast<f32x4*>(dst + (idx / (CK / 4)) * CP + c4off) = v;
     }
+    hook(w, k / nchunks_l, c0 + CK >= cin_pad);
     // barrier k: buffer k&1 is full; the compute waves finished reading it two chunks ago
     __syncthreads();
     c0 += CK;
@@ -361,8 +371,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_ws_ker
 // each compute wave owns 32 pairs x 32 couts with 4 position accumulators (64 registers).
 // "taps" of the packed weights = 3 (ky) x 4 (positions): U[ky][v] = sum_kx G[v][kx] w[ky][kx].
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0>
-__global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_kernel(const ConvArgs a, const ConvWork wk) {
+template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0, int MINW = 1>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_wino_kernel(const ConvArgs a, const ConvWork wk) {
   constexpr int PH = TH + 2, PW = TW + 2, CP = CK + 4;
   constexpr int NCW = WAVES_M * WAVES_N;
   constexpr int BUF = PH * PW * CP;
@@ -376,8 +386,51 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
   const int nchunks = (cin_pad + CK - 1) / CK;
   const int my_items = wk.total > (int)blockIdx.x ? (wk.total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int ktotal = my_items * nchunks;
+  // Residual staging: [patch 0][patch 1][res 0][res 1].  With >= 2 Cin chunks per item the loader waves fetch the
+  // item's residual tile (NCW waves x 2 outputs x 32 slots x 32 couts, rows XOR-swizzled on the 16-byte column)
+  // next to its last chunk, so the compute waves' epilogue reads it from LDS instead of waiting ~2-3k cycles for
+  // HBM.  (With one chunk per item the buffer of item i+2 would be refilled while item i is still being read.)
+  constexpr int RES = NCW * 2 * 1024;
+  float* res_base = lds + 2 * BUF;
+  const bool has_res = a.res != nullptr;
+  const bool stage_res = has_res && nchunks >= 2 && (a.out_cs % 4 == 0) && (a.res_cs % 4 == 0);
   if (wave >= NCW) {
-    ws_loader<3, 1, TH, TW, CK, NLW>(a, wk, lds, tid - NCW * 64, ktotal, cin_pad);
+    constexpr int NLT = NLW * 64;
+    constexpr int NIT = (NCW * 512 + NLT - 1) / NLT;
+    const int ltid = tid - NCW * 64;
+    auto hook = [&](int w_item, int seq, bool last) {
+      if (!stage_res || !last) return;
+      const int tile = (w_item / wk.nblk) % wk.n_tiles_total;
+      const int nb = w_item % wk.nblk;
+      const int g = w_item / (wk.nblk * wk.n_tiles_total);
+      if ((a.res_coff + g * a.Cout) % 4 != 0 || (a.out_coff + g * a.Cout) % 4 != 0) return;
+      const int b = tile / wk.tiles_per_frame;
+      const int t = tile - b * wk.tiles_per_frame;
+      const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
+      const float* __restrict__ resb = a.res + (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout;
+      float* dst = res_base + (seq & 1) * RES;
+      f32x4 rv[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int idx = ltid + i * NLT;
+        const int wv = (idx >> 9) % NCW, o = (idx >> 8) & 1, slot = (idx >> 3) & 31, q = idx & 7;
+        const int n_tile = nb * WAVES_N + wv / WAVES_M;
+        const int p = (wv % WAVES_M) * 32 + slot;
+        int oy = ty0 + p / PPR, ox = tx0 + 2 * (p % PPR) + o;
+        oy = oy < a.Ho ? oy : a.Ho - 1;
+        ox = ox < a.Wo ? ox : a.Wo - 1;
+        const int co = ((n_tile + 1) * 32 <= a.Cout ? n_tile * 32 : 0) + 4 * q;
+        rv[i] = *reinterpret_cast<const f32x4*>(resb + (oy * a.Wo + ox) * a.res_cs + co);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int idx = ltid + i * NLT;
+        const int slot = (idx >> 3) & 31, q = idx & 7;
+        if (idx < NCW * 512) *reinterpret_cast<f32x4*>(dst + (idx >> 8) * 1024 + slot * 32 + 4 * (q ^ (slot & 7))) = rv[i];
+      }
+    };
+    ws_loader<3, 1, TH, TW, CK, NLW>(a, wk, lds, ltid, ktotal, cin_pad, hook);
     return;
   }
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
@@ -500,8 +553,20 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_wino_k
       };
       f32x4 rv[2][4];
       if (vec && has_res) {
-        epi_load_res(e, s2p0, wm * 32, n_tile * 32, li, lh, rv[0]);
-        epi_load_res(e, s2p1, wm * 32, n_tile * 32, li, lh, rv[1]);
+        if (stage_res) {   // the loader waves parked the residual tile in LDS next to the last chunk
+          const float* rs = res_base + ((k / nchunks) & 1) * RES + wave * 2048;
+          const int lq = li >> 2, lj = li & 3;
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const int slot = 8 * gq + 4 * lh + lj;
+              rv[o][gq] = *reinterpret_cast<const f32x4*>(rs + o * 1024 + slot * 32 + 4 * (lq ^ (slot & 7)));
+            }
+        } else {
+          epi_load_res(e, s2p0, wm * 32, n_tile * 32, li, lh, rv[0]);
+          epi_load_res(e, s2p1, wm * 32, n_tile * 32, li, lh, rv[1]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (vec) {
@@ -572,18 +637,27 @@ static hipError_t launch_ws(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0>
+template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0, int MINW = 1>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)(TH + 2) * (TW + 2) * (CK + 4) * sizeof(float);
-  static_assert(lds <= 160 * 1024, "two patch buffers must fit the 160 KiB LDS");
+  constexpr size_t lds = 2 * (size_t)(TH + 2) * (TW + 2) * (CK + 4) * sizeof(float) +
+                         2 * (size_t)(WAVES_M * WAVES_N) * 2 * 1024 * sizeof(float);   // 2 patch + 2 residual areas
+  static_assert(lds <= 160 * 1024, "patch and residual buffers must fit the 160 KiB LDS");
   constexpr int NTHREADS = (WAVES_M * WAVES_N + NLW) * 64;
-  auto kern = conv_wino_kernel<TH, TW, WAVES_M, WAVES_N, CK, NLW, ABL>;
+  auto kern = conv_wino_kernel<TH, TW, WAVES_M, WAVES_N, CK, NLW, ABL, MINW>;
   static bool init = false;
   if (!init) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if ((e = ensure_device_info()) != hipSuccess) return e;
+    if (getenv("ACRMI_DEBUG")) {
+      int occ = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, NTHREADS, lds);
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+      fprintf(stderr, "[acrmi] conv_wino<%d,%d,%d,%d,%d,%d>: threads %d lds %zu regs %d occupancy(API) %d blocks/CU\n", TH, TW,
+              WAVES_M, WAVES_N, CK, NLW, NTHREADS, lds, fa.numRegs, occ);
+    }
     init = true;
   }
   ConvWork wk;
@@ -592,7 +666,12 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
   wk.n_tiles_total = wk.tiles_per_frame * a.B;
   wk.nblk = (a.n_tiles + WAVES_N - 1) / WAVES_N;
   wk.total = wk.n_tiles_total * wk.nblk * a.groups;
-  hipLaunchKernelGGL(kern, dim3((unsigned)pick_grid(wk.total, lds)), dim3(NTHREADS), lds, s, a, wk);
+  long grid = pick_grid(wk.total, lds);
+  if (MINW >= 3) {   // register budget allows two co-resident workgroups per CU
+    const long g2 = 2L * g_num_cus;
+    grid = g2 > wk.total ? wk.total : g2;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, a, wk);
   return hipGetLastError();
 }
 
@@ -608,8 +687,8 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     if (n32) return small ? launch_wino<8, 16, 2, 1, 32, 2>(a, s) : launch_wino<16, 16, 4, 1, 32, 2>(a, s);
     // measured (tools/conv_bench.py --wino): the 8x16-pixel tile with 2x2 compute waves beats the 16x16 tile
     // with 4x2 waves (register-limited to 168 VGPRs, spills) on every N>=64 layer: 113-133 vs 93-110 TF-eq
-    if (g_force_cfg == 302) return launch_wino<16, 16, 4, 2, 32, 2>(a, s);
     if (g_force_cfg == 303) return launch_wino<16, 16, 4, 1, 32, 2>(a, s);
+    if (g_force_cfg == 701) return launch_wino<8, 16, 2, 2, 32, 2, 0, 3>(a, s);   // <=168 VGPRs: 2 workgroups per CU
     if (g_force_cfg == 601) return launch_wino<8, 16, 2, 2, 32, 2, 1>(a, s);   // timing ablations (wrong results)
     if (g_force_cfg == 602) return launch_wino<8, 16, 2, 2, 32, 2, 2>(a, s);
     if (g_force_cfg == 603) return launch_wino<8, 16, 2, 2, 32, 2, 3>(a, s);
