@@ -32,7 +32,7 @@ def pkg(sub):
     return importlib.import_module(PKG + '.' + sub)
 
 
-def cpu_baseline(sd, tables, n_frames=8):
+def cpu_baseline(sd, tables, n_frames=16):
     """The oracle (CPU restatement of the reference, oracle/) timed on this box's host cores."""
     from oracle import acr_net, decode as odec, mano as omano
     frames = torch.from_numpy(pkg('synth').make_frames(n_frames, seed=3))
@@ -71,7 +71,13 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # ACRMI_FORCE_DIST=1 exercises the RCCL path (init, all-gather, barriers) even at world size 1 (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get('ACRMI_FORCE_DIST') == '1'
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -91,25 +97,25 @@ def main():
 
     def step():
         eng.forward(frames, out=views)
-        if world > 1:
+        if use_dist:
             return parallel.all_gather_results(flat, B)
         return views
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -154,10 +160,20 @@ def main():
                'roofline': roofline}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, tables)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    else:
+        line = None
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        try:        # RCCL buffers a version banner in C stdio; push it out before the JSON so the JSON is last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)      # last line of stdout, after RCCL's own chatter
 
 
 if __name__ == '__main__':
