@@ -23,7 +23,6 @@ struct acrmi_ctx {
   int max_batch = 0;
   float* att_ws = nullptr;      // attention-pool workspace
   size_t att_ws_floats = 0;
-  float* img_f32 = nullptr;     // unused (U8NORM writes into a program buffer)
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
   std::vector<float*> mano_allocs;

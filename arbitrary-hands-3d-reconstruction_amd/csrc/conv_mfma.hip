@@ -2,8 +2,8 @@
 // fp32 accumulate), im2col-free.
 //
 // Work item = (output tile of one frame, block of output channels, group).  Every kernel here is
-// wave-specialised and persistent: a workgroup = NCW compute waves + NLW loader waves, one or two
-// workgroups per CU walk the work items.  The loader waves stream the halo'd input patch of the next
+// wave-specialised and persistent: a workgroup = NCW compute waves + NLW loader waves, one workgroup
+// per CU walks the work items.  The loader waves stream the halo'd input patch of the next
 // (item, Cin-chunk) HBM -> registers -> LDS (layout [PH][PW][CK+4]; the 4-float pad keeps the compute
 // waves' ds_read_b128 of 32 neighbouring pixels (nearly) bank-conflict free) into the second of two LDS
 // buffers while the compute waves run the MFMAs of the current chunk: the compute waves' in-order vmcnt
