@@ -123,7 +123,7 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       a.cin8 = (op.cin + 7) / 8;
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
-      a.algo = op.flags & 1;
+      a.algo = op.flags & 3;
       HIPCHK(c, launch_conv(a, s));
       return ACRMI_OK;
     }
@@ -378,8 +378,10 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  void* stream) {
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0)
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
-  if (algo != 0 && !(algo == 1 && ksize == 3 && stride == 1))
+  if (algo != 0 && !((algo == 1 || algo == 2) && ksize == 3 && stride == 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-1 convolution", algo);
+  if (algo == 2 && cin <= 16)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 2 (Winograd F(2x2,3x3)) needs more than 16 input channels");
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))
@@ -459,20 +461,26 @@ int acrmi_tune(int key, int value) {
   if (key == 3) { conv_set_phase_delay(value); return ACRMI_OK; }
   static long long* dbg = nullptr;
   if (key == 1) {   // enable (value != 0) / disable the conv kernel's cycle stamps (workgroup 0, wave 0)
-    if (value && !dbg) { if (hipMalloc(&dbg, 64 * sizeof(long long)) != hipSuccess) return ACRMI_EHIP; }
-    if (dbg) (void)hipMemset(dbg, 0, 64 * sizeof(long long));
+    if (value && !dbg) { if (hipMalloc(&dbg, 128 * sizeof(long long)) != hipSuccess) return ACRMI_EHIP; }
+    if (dbg) (void)hipMemset(dbg, 0, 128 * sizeof(long long));
     conv_set_debug(value ? dbg : nullptr);
     return ACRMI_OK;
   }
   if (key == 2) {   // print the stamps of the last conv launch as deltas (device is synchronised first)
     if (!dbg) return ACRMI_OK;
-    long long h[64];
+    long long h[128];
     if (hipDeviceSynchronize() != hipSuccess) return ACRMI_EHIP;
     if (hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return ACRMI_EHIP;
     const int n = (int)h[63];
     printf("conv stamps (%d):", n);
     for (int i = 1; i < n && i < 60; ++i) printf(" %lld", h[i] - h[i - 1]);
     printf("\n");
+    const int nl = (int)h[127];   // loader wave 0 (conv_wino2_kernel only)
+    if (nl > 0) {
+      printf("loader stamps (%d):", nl);
+      for (int i = 1; i < nl && i < 60; ++i) printf(" %lld", h[64 + i] - h[64 + i - 1]);
+      printf("\n");
+    }
     return ACRMI_OK;
   }
   return fail(nullptr, ACRMI_EINVAL, "acrmi_tune: unknown key %d", key);

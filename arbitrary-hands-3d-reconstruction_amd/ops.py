@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .packer import pack_conv, n_tiles_for, winograd_weights
+from .packer import pack_conv, n_tiles_for, winograd_weights, winograd2d_weights
 
 
 def _p(t):
@@ -42,14 +42,15 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     cout = cout_t // groups
     b = np.zeros(cout_t, np.float32) if bias is None else (
         bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
-    if algo == 'winograd':
+    if algo in ('winograd', 'winograd2d'):
         if k != 3 or stride != 1:
             raise ValueError('winograd needs a 3x3 stride-1 convolution')
-        tr = winograd_weights
+        tr = winograd_weights if algo == 'winograd' else winograd2d_weights
     elif algo == 'direct':
         tr = lambda t: t
     else:
-        raise ValueError('algo must be "direct" or "winograd"')
+        raise ValueError('algo must be "direct", "winograd" or "winograd2d"')
+    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2}[algo]
     packed = [pack_conv(tr(w[g * cout:(g + 1) * cout].astype(np.float64)), b[g * cout:(g + 1) * cout])
               for g in range(groups)]
     wp = torch.from_numpy(np.concatenate([p[0] for p in packed])).to(x.device)
@@ -67,7 +68,7 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     L = _lib.lib()
     _lib.check(L.acrmi_conv2d(_p(x), B, H, W, cs, in_coff, cin, _p(wp), _p(bias_t), fstride, _p(residual),
                               residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1], out_coff,
-                              cout, k, stride, int(relu), groups, 1 if algo == 'winograd' else 0, _s(x)))
+                              cout, k, stride, int(relu), groups, algo_id, _s(x)))
     return out
 
 

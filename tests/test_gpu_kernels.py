@@ -99,6 +99,37 @@ def test_conv2d_winograd_matches_torch(ops, case):
         assert out[..., cout:].abs().max().item() == 0.0
 
 
+WINO2D_CASES = [c for c in WINO_CASES if c[1] // c[7] > 16] + [
+    (1, 24, 32, 10, 36, 3, 1, 1, True, True),        # ragged tile rows/cols, Cin = 1.5 chunks
+    (2, 48, 96, 16, 16, 3, 1, 1, False, True),       # n_tiles = 4 with 96 couts (last n-tile empty)
+    (1, 17, 5, 7, 9, 3, 1, 1, True, False),          # odd everything
+]
+
+
+@pytest.mark.parametrize('case', WINO2D_CASES, ids=lambda c: 'wino2d_B%d_%dto%d_%dx%d_g%d' % (c[0], c[1], c[2], c[3], c[4], c[7]))
+def test_conv2d_winograd2d_matches_torch(ops, case):
+    """3x3 stride-1 convolutions through the Winograd F(2x2,3x3) kernel vs an fp64 direct convolution."""
+    B, cin, cout, H, W, k, stride, groups, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 2)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, k, k, generator=g) / np.sqrt(cin // groups * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1, 1, groups)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv2d(ops.to_nhwc(x), w, b, relu=relu, groups=groups, cin=cin // groups, algo='winograd2d',
+                     residual=None if res is None else ops.to_nhwc(res))
+    torch.cuda.synchronize()
+    err = (_nchw(out, cout).double() - ref).abs().max().item()
+    assert err < 5e-5, err          # Winograd F(2x2,3x3) in fp32: ~4x the direct kernel's round-off
+    if out.shape[-1] > cout:
+        assert out[..., cout:].abs().max().item() == 0.0
+
+
 def test_conv2d_channel_slices_and_frame_bias(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 109, 16, 16, generator=g)
@@ -123,6 +154,10 @@ def test_conv2d_rejects_unsupported(ops):
         ops.conv2d(x, torch.zeros(8, 8, 5, 5))
     with pytest.raises(ValueError):
         ops.conv2d(x, torch.zeros(8, 8, 1, 1), stride=2)
+    with pytest.raises(ValueError):     # F(2x2,3x3) needs two 16-channel chunks per work item
+        ops.conv2d(x, torch.zeros(8, 8, 3, 3), algo='winograd2d')
+    with pytest.raises(ValueError):
+        ops.conv2d(x, torch.zeros(8, 8, 3, 3), stride=2, algo='winograd2d')
 
 
 def test_u8norm_bit_exact(ops):
