@@ -21,6 +21,7 @@
 //                       4 products instead of 6 per kernel row; input transform in registers on the A
 //                       fragments (v0=d0-d2, v1=d1+d2, v2=d2-d1, v3=d1-d3), weights pre-transformed on the
 //                       host (G g), output transform (y0=m0+m1+m2, y1=m1-m2-m3) in the epilogue.
+//  * conv_wino2_kernel: 3x3 stride 1 as 2-D Winograd F(2x2,3x3) (2.25x fewer MFMAs) - conv_wino2.inc.
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,6 @@ namespace acrmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static int g_force_cfg = -1;
 void conv_force_cfg(int cfg) { g_force_cfg = cfg; }
@@ -129,6 +129,12 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
     const bool cok = c < a.Cin;
     const int cc = cok ? c : 0;
     f32x4 stage[NLD];
+    if (a.phase_delay == 8) {   // timing ablation: idle loader (wrong results)
+      __syncthreads();
+      c0 += CK;
+      if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
+      continue;
+    }
     // every load in flight before the first LDS write (hipcc otherwise serialises them in rounds)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -623,430 +629,6 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_win
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 stride-1 convolution as 2-D Winograd F(2x2,3x3): 16 products per 2x2 output block instead of 36
-// (2.25x fewer MFMAs).  Work item = 8x16 output pixels (32 slots = 2x2 blocks) x 32*NT couts.
-//  * loader waves do the whole input transform V = B^T d B on their way from HBM to LDS
-//    (layout [16 positions][32 slots][CK+4]); the compute waves' inner loop is ds_read + weight load + MFMA only.
-//  * the 16 positions are split over the 4 compute waves by row: wave py owns positions (py, 0..3), i.e.
-//    4*NT accumulator tiles; A fragments are read from LDS once per workgroup, not once per N-wave.
-//  * output transform: x-fold in registers, y-fold across the 4 waves through LDS (one exchange per item, hung on
-//    the item's last chunk barrier); wave (oy, ox) then owns output parity (oy, ox) of every 2x2 block and runs the
-//    usual bias/residual/ReLU/dwordx4-store epilogue on it.
-// Weights: 16 "taps" U[py][px] = G g G^T (host, fp64).  Needs >= 2 Cin chunks per item (exchange-area reuse).
-// ------------------------------------------------------------------------------------------------
-template <int CK, int NLW>
-__device__ __forceinline__ void wino2_loader(const ConvArgs& a, const ConvWork& wk, float* lds, int ltid, int ktotal,
-                                             int cin_pad) {
-  constexpr int CP = CK + 4, VPOS = 32 * CP, VBUF = 16 * VPOS;
-  // Loader waves form NTEAM teams of NTASK lanes (one (slot, channel-quad) task per lane); team t owns the chunks
-  // k = t (mod NTEAM) and requests the raw 4x4 windows of its next chunk as soon as it has written the current one,
-  // so a request has NTEAM chunk periods (minus one transform) to come back from HBM/MALL.
-  constexpr int NLT = NLW * 64, QPC = CK / 4, NTASK = 32 * QPC;
-  static_assert(NLT % NTASK == 0, "loader waves must split into whole teams");
-  constexpr int NTEAM = NLT / NTASK, NPT = 1;
-  const int abl = a.phase_delay;   // timing ablations (tools/conv_bench.py --phase): 1 prio 0, 2 no transform, 3 no LDS writes
-  if (abl == 1) __builtin_amdgcn_s_setprio(0);
-  else __builtin_amdgcn_s_setprio(3);
-  const int team = __builtin_amdgcn_readfirstlane(ltid / NTASK);
-  ltid -= team * NTASK;
-  // VALU issue slots are scarce next to a saturated matrix pipe (a VALU instruction of a co-resident wave costs
-  // ~20 cycles here), so the loader keeps its per-chunk VALU work to the transform itself: raw buffer loads take
-  // a per-item byte offset per window pixel (halo pixels get an out-of-range offset -> the load returns 0, no
-  // masks) and the chunk's channel offset rides in the scalar offset; LDS stores use immediate offsets.
-  constexpr unsigned POISON = 0x40000000u;   // > any in-frame byte offset (host checks the frame is < 1 GiB)
-  int w = blockIdx.x, c0 = 0;
-  unsigned off[NPT][16];
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, 0, 0x00020000);
-  f32x4 cur[NPT][16];
-  const int frame_bytes = a.H * a.W * a.in_cs * 4;
-  auto advance = [&](int n) {
-    for (int i = 0; i < n; ++i) {
-      c0 += CK;
-      if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
-    }
-  };
-  auto geometry = [&](int w_item) {
-    const ItemPos ip = item_pos(wk, w_item);
-    const int g = ip.g, b = ip.b;
-    const int ty0 = ip.ty * 8, tx0 = ip.tx * 16;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (size_t)b * a.H * a.W * a.in_cs), 0, frame_bytes,
-                                             0x00020000);
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int idx = ltid + i * NLT;
-      const int slot = (idx / QPC) & 31, q = idx % QPC;
-      const int y0 = ty0 + 2 * (slot >> 3) - 1, x0 = tx0 + 2 * (slot & 7) - 1;
-      const unsigned lane_b = (unsigned)(a.in_coff + g * a.Cin + 4 * q) * 4u;
-      unsigned ry[4], cx[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int iy = y0 + r, ix = x0 + r;
-        ry[r] = (iy >= 0 && iy < a.H) ? (unsigned)(iy * a.W * a.in_cs) * 4u + lane_b : POISON;
-        cx[r] = (ix >= 0 && ix < a.W) ? (unsigned)(ix * a.in_cs) * 4u : POISON;
-      }
-#pragma unroll
-      for (int t16 = 0; t16 < 16; ++t16) off[i][t16] = ry[t16 >> 2] + cx[t16 & 3];
-    }
-  };
-  auto issue = [&](f32x4 (&dst)[NPT][16], int c0_) {
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-#pragma unroll
-      for (int t16 = 0; t16 < 16; ++t16) {
-        unsigned vo = off[i][t16];
-        if (c0_ + CK > a.Cin) {   // (uniform) only the chunk that crosses Cin: quads entirely past Cin read as 0
-          if (c0_ + 4 * (int)((ltid + i * NLT) % QPC) >= a.Cin) vo = POISON;
-        }
-        dst[i][t16] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, c0_ * 4, 0));
-      }
-    }
-  };
-  int kown = team;
-  advance(team);
-  const bool stamp = a.dbg && blockIdx.x == 0 && team == 0 && ltid == 0;   // per own chunk: start, data here, written, requested
-  int ns_ = 0;
-  if (stamp) a.dbg[64 + ns_++] = clock64();
-  if (kown < ktotal) {
-    geometry(w);
-    issue(cur, c0);
-  }
-  for (int k = 0; k < ktotal; ++k) {
-    if (stamp && ns_ < 60) a.dbg[64 + ns_++] = clock64();
-    if (k == kown) {
-    float* dst = lds + (k & 1) * VBUF;
-    if (stamp && ns_ < 60) {
-      const float probe = cur[0][15][0];   // wait for the last requested window
-      asm volatile("" ::"v"(probe));
-      a.dbg[64 + ns_++] = clock64();
-    }
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int idx = ltid + i * NLT;
-      const int slot = (idx / QPC) & 31, q = idx % QPC;
-      const int c = c0 + q * 4;
-      f32x4 d[16];
-#pragma unroll
-      for (int t16 = 0; t16 < 16; ++t16) d[t16] = cur[i][t16];
-      if ((a.Cin & 3) && c0 + CK > a.Cin) {   // (uniform) ragged Cin: the quad that straddles Cin keeps its pad lanes 0
-        if (c < a.Cin && c + 3 >= a.Cin) {
-#pragma unroll
-          for (int t16 = 0; t16 < 16; ++t16) {
-            if (c + 1 >= a.Cin) d[t16][1] = 0.f;
-            if (c + 2 >= a.Cin) d[t16][2] = 0.f;
-            d[t16][3] = 0.f;
-          }
-        }
-      }
-      // rows: t[py][c] = B^T d ; then columns: v[py][px] = t B
-      f32x4 t[16];
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        t[0 + c4] = d[0 + c4] - d[8 + c4];
-        t[4 + c4] = d[4 + c4] + d[8 + c4];
-        t[8 + c4] = d[8 + c4] - d[4 + c4];
-        t[12 + c4] = d[4 + c4] - d[12 + c4];
-      }
-      if (abl == 2) {
-#pragma unroll
-        for (int t16 = 0; t16 < 16; ++t16) t[t16] = d[t16];
-      }
-      if (idx < NTASK && abl != 3) {
-        float* o = dst + slot * CP + q * 4;
-        if (abl == 2) {
-#pragma unroll
-          for (int t16 = 0; t16 < 16; ++t16) *reinterpret_cast<f32x4*>(o + t16 * VPOS) = t[t16];
-        } else
-#pragma unroll
-        for (int py = 0; py < 4; ++py) {
-          *reinterpret_cast<f32x4*>(o + (py * 4 + 0) * VPOS) = t[py * 4 + 0] - t[py * 4 + 2];
-          *reinterpret_cast<f32x4*>(o + (py * 4 + 1) * VPOS) = t[py * 4 + 1] + t[py * 4 + 2];
-          *reinterpret_cast<f32x4*>(o + (py * 4 + 2) * VPOS) = t[py * 4 + 2] - t[py * 4 + 1];
-          *reinterpret_cast<f32x4*>(o + (py * 4 + 3) * VPOS) = t[py * 4 + 1] - t[py * 4 + 3];
-        }
-      }
-    }
-      // this team's next chunk: request its raw windows now, NTEAM barriers before they are needed
-      const int wprev = w;
-      advance(NTEAM);
-      kown += NTEAM;
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamp && ns_ < 60) a.dbg[64 + ns_++] = clock64();
-      if (kown < ktotal) {
-        if (w != wprev) geometry(w);
-        issue(cur, c0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamp && ns_ < 60) a.dbg[64 + ns_++] = clock64();
-    }
-    __syncthreads();   // barrier k: buffer k&1 is full
-  }
-  __syncthreads();   // matches the compute waves' final barrier
-  if (stamp) a.dbg[127] = ns_;
-}
-
-template <int NT, int CK, int NLW>
-__global__ __launch_bounds__((4 + NLW) * 64, 1) void conv_wino2_kernel(const ConvArgs a, const ConvWork wk) {
-  constexpr int CP = CK + 4, VPOS = 32 * CP, VBUF = 16 * VPOS, SPC = CK / 8;
-  constexpr int PSTR = 36, PTILE = 32 * PSTR;   // parked tile: [32 slots][32 couts + 4 pad]
-  constexpr int PART_W = 2 * NT * PTILE;        // floats one wave parks: [ox][nt] tiles
-  static_assert(SPC % 2 == 0, "an even number of 8-channel steps per chunk keeps the fragment buffers static");
-  extern __shared__ f32x4 smem4[];
-  float* lds = reinterpret_cast<float*>(smem4);
-  float* part = lds + 2 * VBUF;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: position row / output parity in SGPRs
-  const int cin_pad = a.cin8 * 8;
-  const int nchunks = (cin_pad + CK - 1) / CK;
-  const int my_items = wk.total > (int)blockIdx.x ? (wk.total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int ktotal = my_items * nchunks;
-  if (wave >= 4) {
-    wino2_loader<CK, NLW>(a, wk, lds, tid - 256, ktotal, cin_pad);
-    return;
-  }
-  const int py = wave;
-  const int li = lane & 31, lh = lane >> 5;
-  // The MFMA operands are swapped (weight fragment as A, activation fragment as B), so an accumulator tile is
-  // D[cout][slot]: the lane owns ONE slot (li) and register 4*g + e holds cout 8*g + 4*lh + e - four consecutive
-  // couts per register quad, which the epilogue parks in LDS with one ds_write_b128.
-  // Store side: this wave writes output parity (oy, ox) of every 2x2 block; lane = (block column p8, cout quad q8),
-  // four block rows gq per lane, so 8 lanes cover one pixel's 128-byte line.
-  const int oy = wave >> 1, ox = wave & 1;
-  const int p8 = lane >> 3, q8 = lane & 7;
-  const int lane_pix = oy * a.Wo + 2 * p8 + ox;
-  const int lane_out = lane_pix * a.out_cs + 4 * q8, lane_res = lane_pix * a.res_cs + 4 * q8;
-  const int gs_out = 2 * a.Wo * a.out_cs, gs_res = 2 * a.Wo * a.res_cs;   // block row +1 = two pixel rows down
-  const float ysign = oy ? -1.f : 1.f;
-  f32x16 acc[4][NT];
-  const int voff = (py * 4) * VPOS + li * CP + 4 * lh;
-
-  // Weight fragments: raw buffer loads, lane part (lane * 16 bytes) in the vector offset, everything else - group,
-  // position (py, p), 8-channel step, n-tile - in the SCALAR offset, so the inner loop issues no VALU instruction
-  // at all.  Steps past cin8 re-read the last valid step (their activation fragments are zero).
-  const int tap_b = a.cin8 * a.n_tiles * 1024, step_b = a.n_tiles * 1024;   // bytes per position / per step
-  const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.groups * 16 * tap_b, 0x00020000);
-  const unsigned wlane = lane * 16;
-  int w = blockIdx.x, c0 = 0;
-  struct WStream {          // weights of one item: byte offset of (group, position row py, n-block) + clamped n-tile offsets
-    int base;
-    int nto[NT];
-  };
-  auto wstream = [&](int w_item) -> WStream {
-    const ItemPos ip = item_pos(wk, w_item);
-    WStream ws;
-    ws.base = (ip.g * 16 + py * 4) * tap_b + ip.rest * NT * 1024;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) ws.nto[n] = (ip.rest * NT + n < a.n_tiles ? n : a.n_tiles - 1 - ip.rest * NT) * 1024;
-    return ws;
-  };
-  // One fragment buffer per position, refreshed in place: as soon as the MFMAs of position p of step s are issued,
-  // the activation fragment (LDS) and the NT weight fragments (L2) of position p of step s+1 are requested into the
-  // same registers - a prefetch distance of 3/4 step at half the registers of a double buffer.  The weight stream
-  // runs ahead across chunk and item boundaries (it does not depend on LDS); LDS fragments restart after each barrier.
-  f32x4 aq[4], bq[4][NT];
-  auto loadB = [&](int p, const WStream& ws, int step) {
-    const int so = ws.base + p * tap_b + (step < a.cin8 ? step : a.cin8 - 1) * step_b;
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-      bq[p][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so + ws.nto[n], 0));
-  };
-  WStream wsc = wstream(w);
-  if (ktotal > 0) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) loadB(p, wsc, 0);
-  }
-  const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;   // per chunk: start, MFMAs done, parked, barrier, stored
-  int ns_ = 0;
-  if (stamp) a.dbg[ns_++] = clock64();
-  __syncthreads();   // barrier 0
-  // One Cin chunk.  The chunk body is instantiated three times - an item's first chunk (its very first MFMA per
-  // accumulator takes C = 0, an inline constant, so accumulators are never cleared with VALU moves), middle chunks,
-  // and the last chunk (which carries the epilogue) - and the item loop below strings them together, so no
-  // fragment register ever flows through a control-flow merge (a merge makes hipcc double the fragment buffers
-  // and copy between them).
-  int k = 0;
-  auto chunk = [&](auto first_tag, auto last_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
-    constexpr bool last_chunk = LAST;
-    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-    const float* vb = lds + (k & 1) * VBUF + voff;
-    const int nc0 = LAST ? 0 : c0 + CK, nw = LAST ? w + (int)gridDim.x : w;
-    const bool more = k + 1 < ktotal;
-    const WStream wsn = (LAST && more) ? wstream(nw) : wsc;
-    const int nstep0 = nc0 / 8;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) aq[p] = *reinterpret_cast<const f32x4*>(vb + p * VPOS);
-    auto step = [&](auto s_tag) {
-      constexpr int s = decltype(s_tag)::value;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            if (FIRST && s == 0 && j == 0) {
-              const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              acc[p][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[p][n][j], aq[p][j], zero, 0, 0, 0);
-            } else {
-              acc[p][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[p][n][j], aq[p][j], acc[p][n], 0, 0, 0);
-            }
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < SPC) {
-          aq[p] = *reinterpret_cast<const f32x4*>(vb + p * VPOS + (s + 1) * 8);
-          loadB(p, wsc, c0 / 8 + s + 1);
-        } else if (!last_chunk) {
-          loadB(p, wsn, nstep0);   // first step of the next chunk; an item's last chunk leaves that to its epilogue
-        }
-      }
-    };
-    static_assert(SPC == 2, "steps per chunk");
-    step(std::integral_constant<int, 0>());
-    step(std::integral_constant<int, 1>());
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-    // ---- item epilogue, first half (before the chunk barrier): residual request, x-fold, park for the y-fold
-    const bool has_res = a.res != nullptr;
-    int rest = 0, ty0 = 0, tx0 = 0;
-    bool full_tile = false;
-    float* out_tile = nullptr;
-    EpiCtx e;
-    f32x4 rv[NT][4], bv[NT];
-    bool vec[NT];
-    auto s2p = [&](int p, bool& ok) -> int {
-      int y = ty0 + 2 * (p >> 3) + oy, x = tx0 + 2 * (p & 7) + ox;
-      ok = y < a.Ho && x < a.Wo;
-      y = y < a.Ho ? y : a.Ho - 1;
-      x = x < a.Wo ? x : a.Wo - 1;
-      return y * a.Wo + x;
-    };
-    if (last_chunk) {
-      const ItemPos ip = item_pos(wk, w);
-      const int g = ip.g, b = ip.b;
-      rest = ip.rest;
-      ty0 = ip.ty * 8;
-      tx0 = ip.tx * 16;
-      e.bias = a.bias + (size_t)g * a.n_tiles * 32 + (size_t)b * a.bias_fstride;
-      e.outb = a.out + (size_t)b * a.Ho * a.Wo * a.out_cs + a.out_coff + g * a.Cout;
-      e.resb = has_res ? a.res + (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout : nullptr;
-      e.res_cs = a.res_cs; e.out_cs = a.out_cs; e.Cout = a.Cout; e.relu = a.relu;
-      e.vec_align = ((a.out_coff + g * a.Cout) % 4 == 0) && (a.out_cs % 4 == 0) &&
-                    (!has_res || (((a.res_coff + g * a.Cout) % 4 == 0) && (a.res_cs % 4 == 0)));
-      full_tile = (ty0 + 8 <= a.Ho) && (tx0 + 16 <= a.Wo);
-      // Tile-relative buffer descriptors: the lane part of an address is a kernel-constant VGPR, everything else a
-      // scalar offset - no 64-bit address pairs in vector registers while the accumulators are still live.
-      const int tile_pix = ty0 * a.Wo + tx0;
-      out_tile = e.outb + (size_t)tile_pix * a.out_cs;
-      const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(has_res ? e.resb + (size_t)tile_pix * a.res_cs : a.in), 0, -1, 0x00020000);
-      const __amdgpu_buffer_rsrc_t brsrc =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.bias), 0, -1, 0x00020000);
-      // residual and bias of the item: requested first (the fragment registers are free - the last step did not
-      // refresh them), consumed after the barrier
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int n_tile = rest * NT + n;
-        vec[n] = full_tile && e.vec_align && ((n_tile + 1) * 32 <= a.Cout);
-        if (vec[n]) {
-          bv[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, 16 * q8, n_tile * 128, 0));
-          if (has_res) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-              rv[n][gq] = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, lane_res * 4, (n_tile * 32 + gq * gs_res) * 4, 0));
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-      // park the x-folded tiles as [slot][cout] (row stride 36 floats): the writer lane holds 4 consecutive couts
-      // per register quad, the reader picks (pixel, cout quad) cells in NHWC store order - the LDS round trip the
-      // y-fold needs anyway doubles as the register transpose
-      float* pw = part + wave * PART_W + li * PSTR + 4 * lh;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const f32x16 r0 = acc[0][n] + acc[1][n] + acc[2][n];
-        const f32x16 r1 = acc[1][n] - acc[2][n] - acc[3][n];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          *reinterpret_cast<f32x4*>(pw + (0 * NT + n) * PTILE + 8 * q) = f32x4{r0[4 * q], r0[4 * q + 1], r0[4 * q + 2], r0[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(pw + (1 * NT + n) * PTILE + 8 * q) = f32x4{r1[4 * q], r1[4 * q + 1], r1[4 * q + 2], r1[4 * q + 3]};
-        }
-      }
-      // the weight fragments of the next item's first step, held back by the last step above, go out now that the
-      // accumulators are dead (the barrier and the second half cover their L2 latency)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) loadB(p, wsn, nstep0);
-    }
-    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-    __syncthreads();   // barrier k+1
-    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-    // ---- second half: y-fold (oy = 0: R0+R1+R2, oy = 1: R1-R2-R3) of this wave's output parity, then store
-    if (last_chunk) {
-      const float* pr = part + (ox * NT) * PTILE + p8 * PSTR + 4 * q8;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int n_tile = rest * NT + n;
-        if (n_tile >= a.n_tiles) continue;
-        f32x4 y[4];   // block row gq, block column p8, couts 4*q8 .. 4*q8+3
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int o = n * PTILE + 8 * gq * PSTR;
-          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pr + (oy + 0) * PART_W + o);
-          const f32x4 p1 = *reinterpret_cast<const f32x4*>(pr + (oy + 1) * PART_W + o);
-          const f32x4 p2 = *reinterpret_cast<const f32x4*>(pr + (oy + 2) * PART_W + o);
-          y[gq] = p0 + ysign * (p1 + p2);
-        }
-        if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-        if (vec[n]) {   // full tile, aligned channel slices: bias, residual, ReLU, one full 128-byte line per 8 lanes
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            f32x4 v = y[gq] + bv[n];
-            if (has_res) v += rv[n][gq];
-            if (a.relu) {
-              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            }
-            // global (not buffer) store: on gfx950 a buffer_store_dwordx4 with an SGPR soffset was observed to pick
-            // up a VALU write to its data registers issued right behind it (hipcc inserts no wait state there)
-            char* ub = reinterpret_cast<char*>(out_tile + n_tile * 32 + gq * gs_out);   // uniform base
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ub + (unsigned)(lane_out * 4)));
-          }
-        } else {        // ragged tile / ragged or unaligned channels: element-wise
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            bool ok;
-            const int pix = s2p(8 * gq + p8, ok);
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-              const int co = n_tile * 32 + 4 * q8 + e4;
-              if (ok && co < a.Cout) {
-                float v = y[gq][e4] + e.bias[co];
-                if (has_res) v += e.resb[(size_t)pix * a.res_cs + co];
-                if (a.relu) v = fmaxf(v, 0.f);
-                e.outb[(size_t)pix * a.out_cs + co] = v;
-              }
-            }
-          }
-        }
-      }
-    }
-    wsc = wsn;
-    c0 = nc0;
-    w = nw;
-    ++k;
-  };
-  for (int item = 0; item < my_items; ++item) {   // nchunks >= 2 (checked by the host)
-    chunk(std::true_type(), std::false_type());
-    for (int ci = 2; ci < nchunks; ++ci) chunk(std::false_type(), std::false_type());
-    chunk(std::false_type(), std::true_type());
-  }
-  if (stamp) a.dbg[63] = ns_;
-}
-
-// ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 static hipError_t ensure_device_info() {
@@ -1133,39 +715,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int NT, int CK, int NLW>
-static hipError_t launch_wino2(const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = (2 * (size_t)16 * 32 * (CK + 4) + 4 * (size_t)2 * NT * 32 * 36) * sizeof(float);
-  static_assert(lds <= 160 * 1024, "two V buffers and the exchange area must fit the 160 KiB LDS");
-  constexpr int NTHREADS = (4 + NLW) * 64;
-  auto kern = conv_wino2_kernel<NT, CK, NLW>;
-  static bool init = false;
-  if (!init) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if ((e = ensure_device_info()) != hipSuccess) return e;
-    if (getenv("ACRMI_DEBUG")) {
-      hipFuncAttributes fa;
-      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
-      fprintf(stderr, "[acrmi] conv_wino2<%d,%d,%d>: threads %d lds %zu regs %d scratch %zu\n", NT, CK, NLW, NTHREADS,
-              lds, fa.numRegs, (size_t)fa.localSizeBytes);
-    }
-    init = true;
-  }
-  if ((a.cin8 * 8 + CK - 1) / CK < 2) return hipErrorInvalidValue;   // exchange area is single-buffered
-  if ((size_t)a.H * a.W * a.in_cs * 4 >= (1u << 30)) return hipErrorInvalidValue;   // loader's halo-poison offsets
-  ConvWork wk;
-  wk.tiles_x = (a.Wo + 15) / 16;
-  wk.tiles_per_frame = wk.tiles_x * ((a.Ho + 7) / 8);
-  wk.n_tiles_total = wk.tiles_per_frame * a.B;
-  wk.nblk = (a.n_tiles + NT - 1) / NT;
-  wk.total = wk.n_tiles_total * wk.nblk * a.groups;
-  if ((unsigned long long)wk.total * (unsigned long long)wk.n_tiles_total >= (1ull << 40)) return hipErrorInvalidValue;
-  set_magics(wk);
-  hipLaunchKernelGGL(kern, dim3((unsigned)pick_grid(wk.total, lds)), dim3(NTHREADS), lds, s, a, wk);
-  return hipGetLastError();
-}
+#include "conv_wino2.inc"
 
 // Tile selection.  N32: one 32-cout tile per wave (Cout <= 32); N64: two.
 // Small frames (<=16x16 outputs) take the 8x16 pixel tile so a batch still fills 256 CUs.
@@ -1176,8 +726,8 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.algo == 2) {   // Winograd F(2x2,3x3): 3x3 stride 1 only, weights packed with 16 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;
-    if (g_force_cfg == 801) return n32 ? launch_wino2<1, 16, 2>(a, s) : launch_wino2<2, 16, 2>(a, s);   // one loader team
-    return n32 ? launch_wino2<1, 16, 4>(a, s) : launch_wino2<2, 16, 4>(a, s);
+    if (g_force_cfg == 801) return n32 ? launch_wino2<1, 32, 4>(a, s) : launch_wino2<2, 32, 4>(a, s);
+    return n32 ? launch_wino2<1, 32, 2>(a, s) : launch_wino2<2, 32, 2>(a, s);
   }
   if (a.algo == 1) {   // Winograd F(2,3) along x: 3x3 stride 1 only, weights packed with 12 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;

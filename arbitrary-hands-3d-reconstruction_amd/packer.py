@@ -90,11 +90,12 @@ def use_winograd(k, stride):
     return k == 3 and stride == 1
 
 
-def conv_algo(k, stride, cin):
-    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3) (needs >= 2 16-channel chunks per work item)."""
+def conv_algo(k, stride, cin, cout):
+    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3) (with more than 32 output channels per group its
+    work items need >= 2 32-channel Cin chunks)."""
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
-    return 2 if (WINOGRAD_2D and cin > 16) else 1
+    return 2 if (WINOGRAD_2D and (cin > 32 or cout <= 32)) else 1
 
 
 class Blob(object):
@@ -178,7 +179,7 @@ class Program(object):
         ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w_ + 2 * (k // 2) - k) // stride + 1
         if out is None:
             out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
-        algo = conv_algo(k, stride, cin)
+        algo = conv_algo(k, stride, cin, cout)
         tr = (lambda t: t, winograd_weights, winograd2d_weights)[algo]
         packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
         w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
