@@ -97,23 +97,36 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   // loader waves are the younger waves on their SIMD: without priority their VMEM issue trails the
   // MFMA stream of the compute wave they share the SIMD with and the patch arrives late
   __builtin_amdgcn_s_setprio(3);
-  int w = blockIdx.x, c0 = 0;
-  // per-item geometry (pixel offsets, halo validity) is computed once per work item; per chunk only the
-  // channel offset changes, so a chunk costs the loader NLD loads + NLD LDS writes and little VALU
+  // Per-item geometry (pixel offsets, halo validity) is computed once per work item; per chunk only the channel
+  // offset changes, so a chunk costs the loader NLD loads + NLD LDS writes and little VALU.
+  // The loads run one chunk ahead of the LDS writes, in two statically named register sets: the requests of chunk
+  // k+1 go out before chunk k is written and the barrier is waited on, so HBM requests stay in flight all the time
+  // (with "load, wait, write, barrier" per chunk the memory-bound layers kept the queue empty half the time).
+  struct Stage {
+    f32x4 v[NLD];
+    unsigned pixok;
+    int c;   // first channel of this lane's float4
+  };
+  int w = blockIdx.x, c0 = 0;        // chunk being written
+  int wn = blockIdx.x, cn0 = 0;      // chunk being requested
   int off[NLD];
-  unsigned pixok = 0;
+  unsigned pixok_n = 0;
   const float* __restrict__ inb = a.in;
   const int c4off = (ltid % (CK / 4)) * 4;
   const int nchunks_l = (cin_pad + CK - 1) / CK;
-  for (int k = 0; k < ktotal; ++k) {
-    if (c0 == 0) {
-      const int tile = (w / wk.nblk) % wk.n_tiles_total;
-      const int g = (w / wk.n_tiles_total) / wk.nblk;
+  const bool idle = a.phase_delay == 8;   // timing ablation: idle loader (wrong results)
+  // request the chunk at (wn, cn0) and advance.  The loads are issued unconditionally (past the last chunk they
+  // re-read the previous addresses): behind a branch hipcc cannot count the loads in flight any more and makes
+  // every later wait a vmcnt(0), which would serialise the two register sets again.
+  auto request = [&](Stage& st, bool valid) {
+    if (valid && cn0 == 0) {
+      const int tile = (wn / wk.nblk) % wk.n_tiles_total;
+      const int g = (wn / wk.n_tiles_total) / wk.nblk;
       const int b = tile / wk.tiles_per_frame;
       const int t = tile - b * wk.tiles_per_frame;
       const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
       inb = a.in + (size_t)b * a.H * a.W * a.in_cs + a.in_coff + g * a.Cin;
-      pixok = 0;
+      pixok_n = 0;
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int idx = ltid + i * NLT;
@@ -122,43 +135,67 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
         const bool ok = (idx < NLOAD) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
         off[i] = (iyc * a.W + ixc) * a.in_cs;   // per-frame offset < 2^31 floats
-        pixok |= (ok ? 1u : 0u) << i;
+        pixok_n |= (ok ? 1u : 0u) << i;
       }
     }
-    const int c = c0 + c4off;
-    const bool cok = c < a.Cin;
-    const int cc = cok ? c : 0;
-    f32x4 stage[NLD];
-    if (a.phase_delay == 8) {   // timing ablation: idle loader (wrong results)
-      __syncthreads();
-      c0 += CK;
-      if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
-      continue;
-    }
-    // every load in flight before the first LDS write (hipcc otherwise serialises them in rounds)
+    st.pixok = pixok_n;
+    st.c = cn0 + c4off;
+    const int cc = st.c < a.Cin ? st.c : 0;
+    // every load in flight before anything else (hipcc otherwise serialises them in rounds)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const f32x4*>(inb + off[i] + cc);
+    for (int i = 0; i < NLD; ++i) st.v[i] = *reinterpret_cast<const f32x4*>(inb + off[i] + cc);
     __builtin_amdgcn_sched_barrier(0);
+    if (valid) {
+      cn0 += CK;
+      if (cn0 >= cin_pad) { cn0 = 0; wn += gridDim.x; }
+    }
+  };
+  auto write = [&](const Stage& st, int k) {   // chunk k = (w, c0) -> LDS buffer k&1, then barrier k
     float* dst = lds + (k & 1) * BUF;
+    const int c = st.c;
+    const bool cok = c < a.Cin;
     const bool ragged_c = cok && (c + 3 >= a.Cin);   // this float4 straddles Cin
+    if (!idle) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = ltid + i * NLT;
-      f32x4 v = stage[i];
-      if (ragged_c) {
-        if (c + 1 >= a.Cin) v[1] = 0.f;
-        if (c + 2 >= a.Cin) v[2] = 0.f;
-        v[3] = 0.f;
+      for (int i = 0; i < NLD; ++i) {
+        const int idx = ltid + i * NLT;
+        f32x4 v = st.v[i];
+        if (ragged_c) {
+          if (c + 1 >= a.Cin) v[1] = 0.f;
+          if (c + 2 >= a.Cin) v[2] = 0.f;
+          v[3] = 0.f;
+        }
+        if (!cok || !((st.pixok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < NLOAD) *reinterpret_cast<f32x4*>(dst + (idx / (CK / 4)) * CP + c4off) = v;
       }
-      if (!cok || !((pixok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < NLOAD) *reinterpret_cast<f32x4*>(dst + (idx / (CK / 4)) * CP + c4off) = v;
     }
     hook(w, k / nchunks_l, c0 + CK >= cin_pad);
     // barrier k: buffer k&1 is full; the compute waves finished reading it two chunks ago
     __syncthreads();
     c0 += CK;
     if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
+  };
+  // (the run-ahead needs 2 x NLD float4 registers: kernels with big patches or a residual hook stay sequential)
+  constexpr bool RUN_AHEAD = NLD <= 16 && std::is_same<Hook, NoHook>::value;
+  Stage s0, s1;
+  if constexpr (RUN_AHEAD) {
+    if (ktotal > 0) {
+      request(s0, true);
+      for (int k = 0; k < ktotal; k += 2) {
+        request(s1, k + 1 < ktotal);
+        write(s0, k);
+        if (k + 1 < ktotal) {
+          request(s0, k + 2 < ktotal);
+          write(s1, k + 1);
+        }
+      }
+    }
+  } else {
+    for (int k = 0; k < ktotal; ++k) {
+      request(s0, true);
+      write(s0, k);
+    }
   }
   __syncthreads();   // matches the compute waves' final barrier
 }
