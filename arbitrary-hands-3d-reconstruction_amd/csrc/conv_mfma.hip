@@ -753,6 +753,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 }
 
 #include "conv_wino2.inc"
+#include "conv_ws2.inc"
 
 // Tile selection.  N32: one 32-cout tile per wave (Cout <= 32); N64: two.
 // Small frames (<=16x16 outputs) take the 8x16 pixel tile so a batch still fills 256 CUs.
@@ -783,6 +784,14 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     if (g_force_cfg == 201) return launch_ws<3, 1, 16, 16, 4, 2, 1, 2, 32, 4>(a, s);
     if (g_force_cfg == 202) return launch_ws<3, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s);
     return small ? launch_ws<3, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s) : launch_ws<3, 1, 16, 16, 4, 2, 1, 2, 32, 2>(a, s);
+  }
+  if (a.ks == 3 && a.stride == 2 && g_force_cfg != 900) {
+    if (n32) return launch_ws2<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
+    return launch_ws2<3, 2, 8, 16, 2, 2, 2, 1, 16, 2>(a, s);
+  }
+  if (a.ks == 1 && a.stride == 1 && g_force_cfg != 900) {
+    if (n32) return small ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s) : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
+    return small ? launch_ws2<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s) : launch_ws2<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
   }
   if (a.ks == 3 && a.stride == 2) {
     if (n32) return launch_ws<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
