@@ -1,0 +1,21 @@
+#!/bin/bash
+# Regenerates the rocprofv3 evidence under gpurun_out/ on a GPU box (run from the repo root through gpurun):
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/profile_round.sh r02'
+# then copy gpurun_out/<tag>_* into profiles/.  Kernel timing and the PMC passes are separate runs (rocprofv3 --pmc
+# must not be combined with other trace domains on this pool).
+set -u
+TAG=${1:-rXX}
+R=$(pwd)
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --no-cpu-baseline"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/${TAG}_stats" -o bench -- $BENCH --steps 5 --warmup 2 > "$OUT/${TAG}_stats.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/${TAG}_pmc_fetch" -o p -- $BENCH --steps 1 --warmup 1 > "$OUT/${TAG}_pmc_fetch.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/${TAG}_pmc_write" -o p -- $BENCH --steps 1 --warmup 1 > "$OUT/${TAG}_pmc_write.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d "$OUT/${TAG}_pmc_mfma" -o p -- $BENCH --steps 1 --warmup 1 > "$OUT/${TAG}_pmc_mfma.log" 2>&1
+cd "$R"
+cp "$(find "$OUT/${TAG}_stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
+python tools/summarize_pmc.py "$OUT/${TAG}_pmc_fetch" "$OUT/${TAG}_pmc_write" "$OUT/${TAG}_hbm_traffic.json" > /dev/null
+tail -1 "$OUT/${TAG}_stats.log" | cut -c1-200
+head -8 "$OUT/${TAG}_bench_kernel_stats.csv"
