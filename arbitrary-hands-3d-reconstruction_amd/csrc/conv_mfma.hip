@@ -42,6 +42,7 @@ static int g_num_cus = 0;
 
 struct ConvWork {
   int tiles_x, tiles_per_frame, n_tiles_total, nblk, total;
+  int nb_inner = 1;   // conv_ws2_kernel, single-chunk items: n-blocks run per item from one LDS patch (nblk is then 1)
   // ceil(2^40 / d) for the four divisors above: item -> (n-block, tile, group, frame, tile row/col) on the scalar
   // unit (hipcc lowers a 32-bit division of uniform values to ~25 VALU instructions, and VALU slots next to a
   // saturated matrix pipe are the scarce resource).  Exact while n * d < 2^40.
