@@ -380,9 +380,6 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
   if (algo != 0 && !((algo == 1 || algo == 2) && ksize == 3 && stride == 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-1 convolution", algo);
-  if (algo == 2 && cin <= 32 && cout > 32)
-    return fail(nullptr, ACRMI_EINVAL,
-                "acrmi_conv2d: algo 2 (Winograd F(2x2,3x3)) with more than 32 output channels needs more than 32 input channels");
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))

@@ -765,8 +765,11 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.algo == 2) {   // Winograd F(2x2,3x3): 3x3 stride 1 only, weights packed with 16 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;
-    if (g_force_cfg == 801) return n32 ? launch_wino2<1, 32, 4>(a, s) : launch_wino2<2, 32, 4>(a, s);
-    return n32 ? launch_wino2<1, 32, 2>(a, s) : launch_wino2<2, 32, 2>(a, s);
+    // two n-tiles per wave need two Cin chunks per item (single-buffered exchange area); Cin <= 32 runs one
+    // n-tile per wave and one 32-cout block per work item instead
+    const bool nt1 = n32 || a.cin8 * 8 <= 32;
+    if (g_force_cfg == 801) return nt1 ? launch_wino2<1, 32, 4>(a, s) : launch_wino2<2, 32, 4>(a, s);
+    return nt1 ? launch_wino2<1, 32, 2>(a, s) : launch_wino2<2, 32, 2>(a, s);
   }
   if (a.algo == 1) {   // Winograd F(2,3) along x: 3x3 stride 1 only, weights packed with 12 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;

@@ -20,7 +20,7 @@ struct ConvArgs {
   int cin8;             // ceil(Cin/8)
   int bias_fstride;     // floats between frames' bias rows (0 = shared)
   int algo;             // 0 direct; 1 Winograd F(2,3) along x (3x3 stride 1, weights packed with 3x4 taps);
-                        // 2 Winograd F(2x2,3x3) (3x3 stride 1, Cin > 32 or Cout <= 32, weights packed with 4x4 taps)
+                        // 2 Winograd F(2x2,3x3) (3x3 stride 1, weights packed with 4x4 taps)
   long long* dbg;       // optional device buffer for cycle stamps (tuning only)
   int phase_delay;      // tuning: cycles the second half of the grid sleeps before starting (0 = off)
 };

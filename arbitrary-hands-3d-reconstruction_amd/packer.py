@@ -91,11 +91,10 @@ def use_winograd(k, stride):
 
 
 def conv_algo(k, stride, cin, cout):
-    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3) (with more than 32 output channels per group its
-    work items need >= 2 32-channel Cin chunks)."""
+    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3)."""
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
-    return 2 if (WINOGRAD_2D and (cin > 32 or cout <= 32)) else 1
+    return 2 if WINOGRAD_2D else 1
 
 
 class Blob(object):

@@ -67,7 +67,7 @@ def main():
         w = (np.random.randn(coutg, cing, k, k) / np.sqrt(cing * k * k)).astype(np.float32)
         wino = 0
         if k == 3 and stride == 1:
-            wino = 2 if (args.wino2 and (cing > 32 or coutg <= 32)) else (1 if (args.wino or args.wino2) else 0)
+            wino = 2 if args.wino2 else (1 if args.wino else 0)
         tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights)[wino]
         packed = [packer.pack_conv(tr(w), np.zeros(coutg, np.float32)) for _ in range(groups)]
         wp = torch.from_numpy(np.concatenate([q[0] for q in packed])).cuda()
