@@ -12,16 +12,16 @@
 // fetches one contiguous 1 KiB line per (tap, 8-channel step, 32-cout tile) straight from L2:
 //   A[i = lane&31][k = lane>>5] = patch[pixel i][ci = 8s + 4*(lane>>5) + j]
 //   B[k = lane>>5][n = lane&31] = W[cout n][ci = 8s + 4*(lane>>5) + j]          j = 0..3
-// Fragments of step i+1 are fetched before the MFMAs of step i (sched_barrier pins that order).
-// Epilogue: folded-BN bias (+ per-frame bias), residual, ReLU; 4x4 DPP transposes inside lane quads turn
-// "lane = cout" into "lane = pixel, 4 regs = 4 couts" so residual/output move as dwordx4.
+// (conv_wino2_kernel / conv_ws2_kernel swap the operands: weights as A, activations as B.)
+// Epilogue: folded-BN bias (+ per-frame bias), residual, ReLU, 16-byte stores.
 //
-//  * conv_ws_kernel   : direct convolution, 3x3 (stride 1/2) and 1x1.
-//  * conv_wino_kernel : 3x3 stride 1 as Winograd F(2,3) along x (1.5x fewer MFMAs): per output-pixel PAIR
-//                       4 products instead of 6 per kernel row; input transform in registers on the A
-//                       fragments (v0=d0-d2, v1=d1+d2, v2=d2-d1, v3=d1-d3), weights pre-transformed on the
-//                       host (G g), output transform (y0=m0+m1+m2, y1=m1-m2-m3) in the epilogue.
-//  * conv_wino2_kernel: 3x3 stride 1 as 2-D Winograd F(2x2,3x3) (2.25x fewer MFMAs) - conv_wino2.inc.
+//  * conv_wino2_kernel: every 3x3 stride-1 conv as 2-D Winograd F(2x2,3x3) (2.25x fewer MFMAs) - conv_wino2.inc.
+//  * conv_ws2_kernel  : direct convolution, 3x3 stride 2, 1x1 (and 3x3 stride 1 on request) - conv_ws2.inc.
+//  * conv_wino_kernel : the previous round's kernel, 3x3 stride 1 as Winograd F(2,3) along x (1.5x fewer MFMAs),
+//                       kept selectable (algo 1): per output-pixel PAIR 4 products instead of 6 per kernel row;
+//                       input transform in registers on the A fragments (v0=d0-d2, v1=d1+d2, v2=d2-d1, v3=d1-d3),
+//                       weights pre-transformed on the host (G g), output transform (y0=m0+m1+m2, y1=m1-m2-m3) and
+//                       4x4 DPP transposes ("lane = cout" -> "lane = pixel, 4 regs = 4 couts") in the epilogue.
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -291,160 +291,6 @@ __device__ __forceinline__ void epi_store_scalar(const EpiCtx& e, Slot2Pix slot2
 }
 
 // ------------------------------------------------------------------------------------------------
-// direct convolution
-// ------------------------------------------------------------------------------------------------
-template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW>
-__global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_ws_kernel(const ConvArgs a, const ConvWork wk) {
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4;
-  constexpr int NCW = WAVES_M * WAVES_N;
-  constexpr int TAPS = KS * KS;
-  constexpr int BUF = PH * PW * CP;
-  static_assert(TH * TW == 32 * MT * WAVES_M, "tile pixels must equal 32*MT*WAVES_M");
-  extern __shared__ f32x4 smem4[];
-  float* lds = reinterpret_cast<float*>(smem4);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cin_pad = a.cin8 * 8;
-  const int nchunks = (cin_pad + CK - 1) / CK;
-  const int my_items = wk.total > (int)blockIdx.x ? (wk.total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int ktotal = my_items * nchunks;
-  if (a.phase_delay > 0 && blockIdx.x * 2 >= gridDim.x) {
-    const long long t_end = clock64() + a.phase_delay;
-    while (clock64() < t_end) __builtin_amdgcn_s_sleep(32);
-  }
-  if (wave >= NCW) {
-    ws_loader<KS, S, TH, TW, CK, NLW>(a, wk, lds, tid - NCW * 64, ktotal, cin_pad);
-    return;
-  }
-  // ================================ compute waves ================================
-  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-  const int li = lane & 31, lh = lane >> 5;
-  f32x16 acc[MT][NTW];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  int aoff[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int p = (wm * MT + m) * 32 + li;
-    aoff[m] = ((p / TW) * S * PW + (p % TW) * S) * CP + 4 * lh;
-  }
-  const size_t tap_stride = (size_t)a.cin8 * a.n_tiles * 256;
-  const size_t step_stride = (size_t)a.n_tiles * 256;
-
-  int w = blockIdx.x, c0 = 0;
-  const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
-  int ns_ = 0;
-  if (stamp) a.dbg[ns_++] = clock64();
-  __syncthreads();   // barrier 0: chunk 0 is in buffer 0
-  if (stamp) a.dbg[ns_++] = clock64();
-  for (int k = 0; k < ktotal; ++k) {
-    const float* patch = lds + (k & 1) * BUF;
-    // item order: N-block fastest, then tile, then group - the N-blocks of one tile run at the same time on
-    // neighbouring workgroups, so the tile's input patch is fetched from HBM once and re-read from MALL/L2
-    const int rest = w % wk.nblk;
-    const int g = w / (wk.nblk * wk.n_tiles_total);
-    const int n_tile0 = (rest * WAVES_N + wn) * NTW;
-    const bool wave_active = n_tile0 < a.n_tiles;
-    const bool last_chunk = c0 + CK >= cin_pad;
-    if (wave_active) {
-      const int nsteps = (cin_pad - c0 < CK ? cin_pad - c0 : CK) / 8;
-      const float* __restrict__ wchunk = a.w + (size_t)g * TAPS * tap_stride + (size_t)n_tile0 * 256 + lane * 4 +
-                                         (size_t)(c0 / 8) * step_stride;
-      f32x4 av[2][MT], bv[2][NTW];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(patch + aoff[m]);
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) bv[0][n] = *reinterpret_cast<const f32x4*>(wchunk + (size_t)n * 256);
-      for (int s = 0; s < nsteps; ++s) {
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int cur = tap & 1, nxt = cur ^ 1;
-          // prefetch the fragments of the next (s, tap); the very last step re-reads a valid address
-          const int ntap = tap + 1 < TAPS ? tap + 1 : 0;
-          const int ns = tap + 1 < TAPS ? s : (s + 1 < nsteps ? s + 1 : s);
-          const int nky = ntap / KS, nkx = ntap % KS;
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            av[nxt][m] = *reinterpret_cast<const f32x4*>(patch + aoff[m] + (nky * PW + nkx) * CP + ns * 8);
-#pragma unroll
-          for (int n = 0; n < NTW; ++n)
-            bv[nxt][n] = *reinterpret_cast<const f32x4*>(wchunk + (size_t)ntap * tap_stride +
-                                                         (size_t)ns * step_stride + (size_t)n * 256);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int n = 0; n < NTW; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m][j], bv[cur][n][j], acc[m][n], 0, 0, 0);
-        }
-        if (TAPS & 1) {   // odd tap count: the double-buffer parity flips every s; re-align
-#pragma unroll
-          for (int m = 0; m < MT; ++m) av[0][m] = av[1][m];
-#pragma unroll
-          for (int n = 0; n < NTW; ++n) bv[0][n] = bv[1][n];
-        }
-      }
-    }
-    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-    // barrier k+1: this buffer may be refilled (chunk k+2); buffer (k+1)&1 holds chunk k+1
-    __syncthreads();
-    if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
-    if (wave_active && last_chunk) {
-      const int tile = (w / wk.nblk) % wk.n_tiles_total;
-      const int b = tile / wk.tiles_per_frame;
-      const int t = tile - b * wk.tiles_per_frame;
-      const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
-      const bool has_res = a.res != nullptr;
-      EpiCtx e;
-      e.bias = a.bias + (size_t)g * a.n_tiles * 32 + (size_t)b * a.bias_fstride;
-      e.outb = a.out + (size_t)b * a.Ho * a.Wo * a.out_cs + a.out_coff + g * a.Cout;
-      e.resb = has_res ? a.res + (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout : nullptr;
-      e.res_cs = a.res_cs; e.out_cs = a.out_cs; e.Cout = a.Cout; e.relu = a.relu;
-      e.vec_align = ((a.out_coff + g * a.Cout) % 4 == 0) && (a.out_cs % 4 == 0) &&
-                    (!has_res || (((a.res_coff + g * a.Cout) % 4 == 0) && (a.res_cs % 4 == 0)));
-      const bool full_tile = (ty0 + TH <= a.Ho) && (tx0 + TW <= a.Wo);
-      auto slot2pix = [&](int p, bool& ok) -> int {
-        int oy = ty0 + p / TW, ox = tx0 + p % TW;
-        ok = full_tile || (oy < a.Ho && ox < a.Wo);
-        oy = oy < a.Ho ? oy : a.Ho - 1;
-        ox = ox < a.Wo ? ox : a.Wo - 1;
-        return oy * a.Wo + ox;
-      };
-      f32x4 rv[MT][NTW][4];
-      bool vec[NTW];
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        vec[n] = e.vec_align && ((n_tile0 + n + 1) * 32 <= a.Cout);
-        if (vec[n] && has_res) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m) epi_load_res(e, slot2pix, (wm * MT + m) * 32, (n_tile0 + n) * 32, li, lh, rv[m][n]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n = 0; n < NTW; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if (vec[n]) epi_store_vec(e, slot2pix, (wm * MT + m) * 32, (n_tile0 + n) * 32, li, lh, acc[m][n], rv[m][n], has_res);
-          else epi_store_scalar(e, slot2pix, (wm * MT + m) * 32, (n_tile0 + n) * 32, li, lh, acc[m][n], has_res);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        }
-    }
-    if (stamp && last_chunk && ns_ < 60) a.dbg[ns_++] = clock64();
-    c0 += CK;
-    if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
-  }
-  if (stamp) a.dbg[63] = ns_;
-}
-
-// ------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution as Winograd F(2,3) along x.  M slots are output-pixel PAIRS (y, 2p | 2p+1);
 // each compute wave owns 32 pairs x 32 couts with 4 position accumulators (64 registers).
 // "taps" of the packed weights = 3 (ky) x 4 (positions): U[ky][v] = sum_kx G[v][kx] w[ky][kx].
@@ -690,31 +536,6 @@ static long pick_grid(long total, size_t lds_bytes) {
   return grid > total ? total : grid;
 }
 
-template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW>
-static hipError_t launch_ws(const ConvArgs& a, hipStream_t s) {
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
-  constexpr size_t lds = 2 * (size_t)PH * PW * (CK + 4) * sizeof(float);
-  static_assert(lds <= 160 * 1024, "two patch buffers must fit the 160 KiB LDS");
-  constexpr int NTHREADS = (WAVES_M * WAVES_N + NLW) * 64;
-  auto kern = conv_ws_kernel<KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW>;
-  static bool init = false;
-  if (!init) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if ((e = ensure_device_info()) != hipSuccess) return e;
-    init = true;
-  }
-  ConvWork wk;
-  wk.tiles_x = (a.Wo + TW - 1) / TW;
-  wk.tiles_per_frame = wk.tiles_x * ((a.Ho + TH - 1) / TH);
-  wk.n_tiles_total = wk.tiles_per_frame * a.B;
-  wk.nblk = (a.n_tiles + WAVES_N * NTW - 1) / (WAVES_N * NTW);
-  wk.total = wk.n_tiles_total * wk.nblk * a.groups;
-  hipLaunchKernelGGL(kern, dim3((unsigned)pick_grid(wk.total, lds)), dim3(NTHREADS), lds, s, a, wk);
-  return hipGetLastError();
-}
-
 template <int TH, int TW, int WAVES_M, int WAVES_N, int CK, int NLW, int ABL = 0, int MINW = 1>
 static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(TH + 2) * (TW + 2) * (CK + 4) * sizeof(float) +
@@ -773,40 +594,22 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   }
   if (a.algo == 1) {   // Winograd F(2,3) along x: 3x3 stride 1 only, weights packed with 12 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;
+    // (the previous round's kernel; the program lowers every 3x3 stride-1 conv to algo 2 now)
     if (n32) return small ? launch_wino<8, 16, 2, 1, 32, 2>(a, s) : launch_wino<16, 16, 4, 1, 32, 2>(a, s);
-    // measured (tools/conv_bench.py --wino): the 8x16-pixel tile with 2x2 compute waves beats the 16x16 tile
-    // with 4x2 waves (register-limited to 168 VGPRs, spills) on every N>=64 layer: 113-133 vs 93-110 TF-eq
-    if (g_force_cfg == 303) return launch_wino<16, 16, 4, 1, 32, 2>(a, s);
-    if (g_force_cfg == 701) return launch_wino<8, 16, 2, 2, 32, 2, 0, 3>(a, s);   // <=168 VGPRs: 2 workgroups per CU
-    if (g_force_cfg == 601) return launch_wino<8, 16, 2, 2, 32, 2, 1>(a, s);   // timing ablations (wrong results)
-    if (g_force_cfg == 602) return launch_wino<8, 16, 2, 2, 32, 2, 2>(a, s);
-    if (g_force_cfg == 603) return launch_wino<8, 16, 2, 2, 32, 2, 3>(a, s);
     return launch_wino<8, 16, 2, 2, 32, 2>(a, s);
   }
+  // direct: template arguments <KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW>
   if (a.ks == 3 && a.stride == 1) {
-    if (n32) return small ? launch_ws<3, 1, 8, 16, 4, 1, 1, 1, 32, 2>(a, s) : launch_ws<3, 1, 16, 16, 4, 2, 1, 1, 32, 2>(a, s);
-    if (g_force_cfg == 201) return launch_ws<3, 1, 16, 16, 4, 2, 1, 2, 32, 4>(a, s);
-    if (g_force_cfg == 202) return launch_ws<3, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s);
-    return small ? launch_ws<3, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s) : launch_ws<3, 1, 16, 16, 4, 2, 1, 2, 32, 2>(a, s);
+    if (n32) return small ? launch_ws2<3, 1, 8, 16, 4, 1, 1, 1, 32, 2>(a, s) : launch_ws2<3, 1, 16, 16, 4, 2, 1, 1, 32, 2>(a, s);
+    return small ? launch_ws2<3, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s) : launch_ws2<3, 1, 16, 16, 4, 2, 1, 2, 32, 2>(a, s);
   }
-  if (a.ks == 3 && a.stride == 2 && g_force_cfg != 900) {
+  if (a.ks == 3 && a.stride == 2) {
     if (n32) return launch_ws2<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
     return launch_ws2<3, 2, 8, 16, 2, 2, 2, 1, 16, 2>(a, s);
   }
-  if (a.ks == 1 && a.stride == 1 && g_force_cfg != 900) {
+  if (a.ks == 1 && a.stride == 1) {
     if (n32) return small ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s) : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
     return small ? launch_ws2<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s) : launch_ws2<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
-  }
-  if (a.ks == 3 && a.stride == 2) {
-    if (n32) return launch_ws<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
-    return launch_ws<3, 2, 8, 16, 2, 2, 2, 1, 16, 2>(a, s);
-  }
-  if (a.ks == 1 && a.stride == 1) {
-    if (n32) return small ? launch_ws<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s) : launch_ws<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
-    if (g_force_cfg == 401) return launch_ws<1, 1, 16, 16, 4, 2, 1, 2, 32, 2>(a, s);
-    if (g_force_cfg == 402) return launch_ws<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s);
-    if (g_force_cfg == 403) return launch_ws<1, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s);
-    return small ? launch_ws<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s) : launch_ws<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
   }
   return hipErrorInvalidValue;
 }
