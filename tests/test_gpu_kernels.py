@@ -151,6 +151,37 @@ def test_conv2d_channel_slices_and_frame_bias(ops):
     assert (dst[..., :5] == 7).all() and (dst[..., 8:] == 7).all()
 
 
+@pytest.mark.parametrize('algo', ['winograd2d', 'direct'])
+def test_conv3x3_channel_slices_frame_bias_residual(ops, algo):
+    """The 3x3 kernels on the buffer conventions the program uses: input read from a channel slice of a wider buffer,
+    output written into an aligned / an unaligned channel slice (neighbour channels untouched), per-frame bias,
+    residual whose last rows end exactly at the end of its tensor (bounded residual descriptor), ragged Cout."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 3, 16, 32
+    xw = torch.randn(B, 80, H, W, generator=g)
+    w = torch.randn(40, 48, 3, 3, generator=g) / np.sqrt(48 * 9)
+    fb = torch.randn(B, 64, generator=g)
+    res = torch.randn(B, 40, H, W, generator=g)
+    ref = F.relu(F.conv2d(xw[:, 32:80].double(), w.double(), None, 1, 1) + fb[:, :40, None, None].double() + res.double())
+    for coff in (8, 5):
+        dst = torch.full((B, H, W, 60), 7.0, device='cuda')
+        ops.conv2d(ops.to_nhwc(xw), w, None, relu=True, cin=48, in_coff=32, out=dst, out_coff=coff,
+                   frame_bias=fb.cuda(), residual=ops.to_nhwc(res), algo=algo)
+        got = dst[..., coff:coff + 40].permute(0, 3, 1, 2).cpu().double()
+        assert (got - ref).abs().max().item() < 5e-5, (algo, coff)
+        assert (dst[..., :coff] == 7).all() and (dst[..., coff + 40:] == 7).all()
+
+
+def test_conv_stride2_groups_and_slices(ops):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 64, 20, 24, generator=g)
+    w = torch.randn(96, 32, 3, 3, generator=g) / np.sqrt(32 * 9)     # 2 groups of 32 -> 48
+    b = torch.randn(96, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), 2, 1, 1, 2)
+    out = ops.conv2d(ops.to_nhwc(x), w, b, stride=2, groups=2, cin=32)
+    assert (_nchw(out, 96).double() - ref).abs().max().item() < 2e-5
+
+
 def test_conv2d_rejects_unsupported(ops):
     x = torch.zeros(1, 8, 8, 8, device='cuda')
     with pytest.raises(ValueError):
