@@ -37,7 +37,7 @@ class HeadLayout(C.Structure):
 EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy', 'acrmi_load_weights',
            'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
-           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess']
+           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans']
 
 _lib = None
 
@@ -83,6 +83,7 @@ def lib():
     L.acrmi_profile_ops.argtypes = [vp, u8p, i32, vp, i32, vp]
     L.acrmi_tune.argtypes = [i32, i32]
     L.acrmi_preprocess.argtypes = [u8p, i32, i32, i32, u8p, vp, vp]
+    L.acrmi_cam_trans.argtypes = [f32p, f32p, i32, C.c_float, C.c_float, f32p, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr'):

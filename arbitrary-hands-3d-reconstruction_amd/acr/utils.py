@@ -163,9 +163,13 @@ def estimate_translation_np(joints_3d, joints_2d, joints_conf, focal_length=600,
 
 
 def estimate_translation(joints_3d, pj2d, focal_length=600, img_size=np.array([512., 512.])):
-    """Per-hand cam_trans on the host (acr/utils.py:399-412,474-519): 2D targets are (pj2d+1)*256.
+    """Per-hand cam_trans (acr/utils.py:399-412,474-519): 2D targets are (pj2d+1)*256.
     The reference tries cv2 EPnP+RANSAC first (non-deterministic, render-only); this build always takes
-    the reference's deterministic least-squares branch."""
+    the reference's deterministic least-squares branch - on the device (acrmi_cam_trans) for device tensors,
+    with the numpy restatement below for host tensors."""
+    if joints_3d.is_cuda:
+        from .. import ops
+        return ops.cam_trans(joints_3d, pj2d, focal_length=focal_length, img_size=float(np.asarray(img_size).reshape(-1)[0]))
     j3 = joints_3d.detach().cpu().numpy().astype(np.float64)
     j2 = (pj2d.detach().cpu().numpy().astype(np.float64) + 1) * 256
     trans = np.zeros((j3.shape[0], 3))

@@ -454,6 +454,14 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "attpool: %s", hipGetErrorString(e));
 }
 
+int acrmi_cam_trans(const float* joints_dev, const float* pj2d_dev, int n, float focal_length, float img_size,
+                    float* trans_dev, void* stream) {
+  if (n < 0 || (n > 0 && (!joints_dev || !pj2d_dev || !trans_dev)) || !(focal_length > 0.f) || !(img_size > 0.f))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_cam_trans: bad arguments");
+  hipError_t e = launch_cam_trans(joints_dev, pj2d_dev, n, focal_length, img_size, trans_dev, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "cam_trans: %s", hipGetErrorString(e));
+}
+
 int acrmi_tune(int key, int value) {
   if (key == 0) { conv_force_cfg(value); return ACRMI_OK; }
   if (key == 3) { conv_set_phase_delay(value); return ACRMI_OK; }

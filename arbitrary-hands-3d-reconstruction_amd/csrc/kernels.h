@@ -97,5 +97,6 @@ struct ManoArgs {
   float *verts_camed, *pj2d, *pj2d_org;
 };
 hipError_t launch_mano(const ManoArgs& a, hipStream_t s);
+hipError_t launch_cam_trans(const float* joints, const float* pj2d, int n, float focal, float img, float* out, hipStream_t s);
 
 }  // namespace acrmi

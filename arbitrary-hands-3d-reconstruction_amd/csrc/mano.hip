@@ -183,4 +183,51 @@ hipError_t launch_mano(const ManoArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Camera translation per hand: the reference's closed-form least squares (acr/utils.py:430-472,
+// estimate_translation_np with unit confidences): for every joint (X, Y, Z) with 2-D target (u, v) = (pj2d+1)*img/2
+//   f*tx + (c-u)*tz = (u-c)*Z - f*X,   f*ty + (c-v)*tz = (v-c)*Z - f*Y,   c = img/2
+// solved through the 3x3 normal equations in fp64 (the reference does the same in numpy fp64).  One thread per hand.
+__global__ void cam_trans_kernel(const float* __restrict__ joints, const float* __restrict__ pj2d, int n, double f,
+                                 double img, float* __restrict__ out) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n) return;
+  const double c = img / 2;
+  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, b[3] = {0, 0, 0};
+  for (int j = 0; j < 21; ++j) {
+    const double X = joints[(size_t)h * 63 + j * 3], Y = joints[(size_t)h * 63 + j * 3 + 1], Z = joints[(size_t)h * 63 + j * 3 + 2];
+    const double u = ((double)pj2d[(size_t)h * 42 + j * 2] + 1) * c, v = ((double)pj2d[(size_t)h * 42 + j * 2 + 1] + 1) * c;
+    const double r0[3] = {f, 0, c - u}, r1[3] = {0, f, c - v};
+    const double c0 = (u - c) * Z - f * X, c1 = (v - c) * Z - f * Y;
+    for (int p = 0; p < 3; ++p) {
+      for (int q = 0; q < 3; ++q) A[p][q] += r0[p] * r0[q] + r1[p] * r1[q];
+      b[p] += r0[p] * c0 + r1[p] * c1;
+    }
+  }
+  // Gaussian elimination with partial pivoting
+  double M[3][4] = {{A[0][0], A[0][1], A[0][2], b[0]}, {A[1][0], A[1][1], A[1][2], b[1]}, {A[2][0], A[2][1], A[2][2], b[2]}};
+  for (int col = 0; col < 3; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 3; ++r)
+      if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+    for (int q = 0; q < 4; ++q) { const double t = M[col][q]; M[col][q] = M[piv][q]; M[piv][q] = t; }
+    for (int r = col + 1; r < 3; ++r) {
+      const double m = M[r][col] / M[col][col];
+      for (int q = col; q < 4; ++q) M[r][q] -= m * M[col][q];
+    }
+  }
+  double t[3];
+  for (int r = 2; r >= 0; --r) {
+    double s = M[r][3];
+    for (int q = r + 1; q < 3; ++q) s -= M[r][q] * t[q];
+    t[r] = s / M[r][r];
+  }
+  for (int d = 0; d < 3; ++d) out[(size_t)h * 3 + d] = (float)t[d];
+}
+
+hipError_t launch_cam_trans(const float* joints, const float* pj2d, int n, float focal, float img, float* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cam_trans_kernel, dim3((n + 63) / 64), dim3(64), 0, s, joints, pj2d, n, (double)focal, (double)img, out);
+  return hipGetLastError();
+}
+
 }  // namespace acrmi

@@ -86,6 +86,19 @@ def preprocess(bgr_frames):
     return out, torch.from_numpy(offsets)
 
 
+def cam_trans(joints, pj2d, focal_length=600.0, img_size=512.0):
+    """joints [n,21,3], pj2d [n,21,2] (device fp32) -> cam_trans [n,3]: the reference's closed-form least squares
+    (acr/utils.py:430-472, unit confidences) on the device."""
+    _need_cuda(joints, pj2d)
+    n = joints.shape[0]
+    if tuple(joints.shape[1:]) != (21, 3) or tuple(pj2d.shape) != (n, 21, 2):
+        raise ValueError('joints must be [n,21,3] and pj2d [n,21,2]')
+    out = torch.empty(n, 3, dtype=torch.float32, device=joints.device)
+    j, p = joints.contiguous().float(), pj2d.contiguous().float()
+    _lib.check(_lib.lib().acrmi_cam_trans(_p(j), _p(p), n, float(focal_length), float(img_size), _p(out), _s(joints)))
+    return out
+
+
 def u8norm(img):
     _need_cuda(img)
     B, H, W, _ = img.shape

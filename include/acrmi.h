@@ -147,6 +147,12 @@ int acrmi_mano(acrmi_ctx* ctx, const float* poses, int pose_stride, const float*
                const float* cam, int cam_stride, const float* offsets, float* verts_camed, float* pj2d,
                float* pj2d_org, void* stream);
 
+/* acr/utils.py:430-472 + :474-519 (estimate_translation_np / estimate_translation, the reference's closed-form
+ * least-squares branch, unit joint confidences): joints [n,21,3] and pj2d [n,21,2] (in [-1,1]; the 2-D targets are
+ * (pj2d+1)*img_size/2) on the device -> cam_trans [n,3].  Solved in fp64 like the reference. */
+int acrmi_cam_trans(const float* joints_dev, const float* pj2d_dev, int n, float focal_length, float img_size,
+                    float* trans_dev, void* stream);
+
 /* acr/main.py:126-141 + :85 in one call: frames -> slots [B,2,ACRMI_SLOT], verts [B,2,778,3],
  * joints [B,2,21,3] (root-aligned on joint 9, metres).  offsets_dev [B,10] may be NULL. */
 int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* offsets_dev, float* slots_dev,

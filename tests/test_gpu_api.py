@@ -97,6 +97,28 @@ def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
     assert acr2(np.ascontiguousarray(frames2[0][:, :, ::-1]), 'n.jpg') == {'n.jpg': {}}
 
 
+def test_cam_trans_kernel_matches_reference_least_squares():
+    """§8f-3: acrmi_cam_trans == the reference's closed-form least squares (acr/utils.py:430-472; restated in numpy
+    fp64 in acr.utils.estimate_translation_np and pinned against the reference's cam_trans in test_host_api)."""
+    u, ops = pkg('acr.utils'), pkg('ops')
+    rs = np.random.RandomState(3)
+    n = 37
+    j3 = (rs.randn(n, 21, 3) * 0.08).astype(np.float32)
+    t_true = np.stack([rs.uniform(-0.3, 0.3, n), rs.uniform(-0.3, 0.3, n), rs.uniform(0.4, 3.0, n)], 1)
+    f = 1265.0
+    p = j3.astype(np.float64) + t_true[:, None]
+    pj2d = ((f * p[..., :2] / p[..., 2:] + 256) / 256 - 1 + rs.randn(n, 21, 2) * 2e-3).astype(np.float32)
+    want = np.stack([u.estimate_translation_np(j3[i].astype(np.float64), (pj2d[i].astype(np.float64) + 1) * 256,
+                                               np.ones(21, np.float32), focal_length=f) for i in range(n)])
+    got = ops.cam_trans(torch.from_numpy(j3).cuda(), torch.from_numpy(pj2d).cuda(), focal_length=f).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    assert np.abs(got - t_true).max() < 0.05                       # and it recovers the translation
+    assert ops.cam_trans(torch.zeros(0, 21, 3).cuda(), torch.zeros(0, 21, 2).cuda()).shape == (0, 3)
+    # the product path (MANOWrapper -> estimate_translation) takes the device kernel for device tensors
+    t2 = u.estimate_translation(torch.from_numpy(j3).cuda(), torch.from_numpy(pj2d).cuda(), focal_length=f)
+    assert t2.is_cuda and np.allclose(t2.cpu().numpy(), got)
+
+
 def test_gpu_preprocess_matches_host_preprocess():
     """§8f-1: the HIP pre-processing kernel == acr.utils.img_preprocess (white pad + bicubic a=-0.75) on the same
     frames; cv2 itself is not available here, so parity with OpenCV's fixed-point INTER_CUBIC stays unpinned."""
