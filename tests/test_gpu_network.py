@@ -103,6 +103,42 @@ def test_forward_matches_oracle_and_is_batch_invariant(engine, frames2, oracle_m
             assert np.abs(out2['joints'][b, h].cpu().numpy() - j[0]).max() < 1e-4
 
 
+def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
+    """BASELINE.json's bench configuration (batch 64, 512x512): size-independent properties of the whole path.
+    Frames are independent, so (i) the two golden frames planted anywhere in the batch of 64 reproduce the reference's
+    vertices within the 1e-4 m budget and are bit-identical to their batch-2 run and to each other's copies - whichever
+    CU / work item they land on; (ii) running the batch twice is bit-identical (no races, no atomics-order effects);
+    (iii) a permutation of the frames permutes the outputs."""
+    g = golden('e2e_batch1.npz')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=64)
+    eng.load_mano(_flip_left(mano_tables))
+    rnd = pkg('synth').make_frames(64, seed=9, structured=False)
+    spots = {0: (0, 17, 63), 1: (1, 31, 62)}          # golden frame -> positions in the batch
+    for b, pos in spots.items():
+        for p in pos:
+            rnd[p] = frames2[b]
+    x = torch.from_numpy(rnd).cuda()
+    out = {k: v.clone() for k, v in eng.forward(x).items()}
+    again = eng.forward(x)
+    torch.cuda.synchronize()
+    for k in ('slots', 'verts', 'joints'):
+        assert torch.equal(out[k], again[k]), k
+        assert torch.isfinite(out[k]).all(), k
+    small = eng.forward(torch.from_numpy(frames2).cuda())
+    for b, pos in spots.items():
+        for p in pos:
+            assert torch.equal(out['verts'][p], small['verts'][b])
+            assert torch.equal(out['slots'][p], small['slots'][b])
+            assert np.abs(out['verts'][p].cpu().numpy() - g['f%d_verts' % b]).max() < 1e-4
+            assert np.abs(out['joints'][p].cpu().numpy() - g['f%d_j3d' % b]).max() < 1e-4
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(1))
+    outp = eng.forward(x[perm.cuda()].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(outp['verts'], out['verts'][perm.cuda()])
+    eng.close()
+
+
 def test_engine_argument_errors(engine):
     with pytest.raises(ValueError):
         engine.forward(torch.zeros(1, 256, 256, 3, dtype=torch.uint8).cuda())
