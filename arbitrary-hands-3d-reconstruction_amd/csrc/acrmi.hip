@@ -259,10 +259,15 @@ int acrmi_backbone_heads(acrmi_ctx* c, const uint8_t* img, int B, void* stream) 
   if (!c || !img) return fail(c, ACRMI_EINVAL, "acrmi_backbone_heads: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_heads: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  static const bool dbg_sync = getenv("ACRMI_DEBUG_SYNC") != nullptr;   // attribute a fault/hang to an op
+  int i = 0;
   for (const acrmi_op& op : c->ops) {
+    ++i;
     if (op.kind == ACRMI_OP_COORDFILL) continue;
+    if (dbg_sync) fprintf(stderr, "[acrmi] op %d kind %d B %d\n", i - 1, (int)op.kind, B), fflush(stderr);
     int r = run_op(c, op, img, B, (hipStream_t)stream);
     if (r) return r;
+    if (dbg_sync) HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
   }
   return ACRMI_OK;
 }

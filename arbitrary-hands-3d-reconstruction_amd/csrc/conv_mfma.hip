@@ -77,6 +77,17 @@ __device__ __forceinline__ ItemPos item_pos(const ConvWork& wk, int w) {
   return p;
 }
 
+// Bytes of bias behind group g's origin inside one bias row.  The epilogues read whole 32-channel n-tiles through a
+// buffer descriptor; a per-frame bias row is only bias_fstride floats long (< n_tiles*32 for a ragged Cout), so the
+// descriptor ends at the row: the tail channels read 0 (they are masked at the store) instead of running past the
+// last frame's row and off the allocation.
+__device__ __forceinline__ int bias_row_left(const ConvArgs& a, int g) {
+  const int packed = a.groups * a.n_tiles * 32;
+  const int row = (a.bias_fstride && a.bias_fstride < packed) ? a.bias_fstride : packed;
+  const int left = row - g * a.n_tiles * 32;
+  return left > 0 ? left * 4 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // loader waves: fill LDS buffer (k & 1) with the patch of chunk k, one workgroup barrier per chunk
 // ------------------------------------------------------------------------------------------------
@@ -119,7 +130,10 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   // request the chunk at (wn, cn0) and advance.  The loads are issued unconditionally (past the last chunk they
   // re-read the previous addresses): behind a branch hipcc cannot count the loads in flight any more and makes
   // every later wait a vmcnt(0), which would serialise the two register sets again.
-  auto request = [&](Stage& st, bool valid) {
+  // geometry of the item the next request starts (if it starts one).  ~10 VALU instructions per load, and a loader
+  // wave's VALU only issues while the MFMA wave it shares the SIMD with stalls - so this runs in the slack before a
+  // barrier (see the loop below), never between a request and the LDS write the compute waves are waiting for.
+  auto prepare = [&](bool valid) {
     if (valid && cn0 == 0) {
       const int tile = (wn / wk.nblk) % wk.n_tiles_total;
       const int g = (wn / wk.n_tiles_total) / wk.nblk;
@@ -139,6 +153,8 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
         pixok_n |= (ok ? 1u : 0u) << i;
       }
     }
+  };
+  auto request = [&](Stage& st, bool valid) {   // prepare() for this position has run
     st.pixok = pixok_n;
     st.c = cn0 + c4off;
     const int cc = st.c < a.Cin ? st.c : 0;
@@ -152,7 +168,8 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       if (cn0 >= cin_pad) { cn0 = 0; wn += gridDim.x; }
     }
   };
-  auto write = [&](const Stage& st, int k) {   // chunk k = (w, c0) -> LDS buffer k&1, then barrier k
+  // chunk k = (w, c0) -> LDS buffer k&1, geometry for the next request (prep), then barrier k
+  auto write = [&](const Stage& st, int k, bool prep) {
     float* dst = lds + (k & 1) * BUF;
     const int c = st.c;
     const bool cok = c < a.Cin;
@@ -172,6 +189,7 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       }
     }
     hook(w, k / nchunks_l, c0 + CK >= cin_pad);
+    prepare(prep);
     // barrier k: buffer k&1 is full; the compute waves finished reading it two chunks ago
     __syncthreads();
     c0 += CK;
@@ -182,20 +200,23 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   Stage s0, s1;
   if constexpr (RUN_AHEAD) {
     if (ktotal > 0) {
+      prepare(true);
       request(s0, true);
+      prepare(ktotal > 1);
       for (int k = 0; k < ktotal; k += 2) {
         request(s1, k + 1 < ktotal);
-        write(s0, k);
+        write(s0, k, k + 2 < ktotal);
         if (k + 1 < ktotal) {
           request(s0, k + 2 < ktotal);
-          write(s1, k + 1);
+          write(s1, k + 1, k + 3 < ktotal);
         }
       }
     }
   } else {
+    prepare(ktotal > 0);
     for (int k = 0; k < ktotal; ++k) {
       request(s0, true);
-      write(s0, k);
+      write(s0, k, k + 1 < ktotal);
     }
   }
   __syncthreads();   // matches the compute waves' final barrier
