@@ -6,7 +6,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libacrmi.so')
 
-OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL = range(1, 9)
+OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS = range(1, 10)
+MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
+OPT_POINT_HEADS = 1
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
 E_INVAL, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
@@ -26,7 +28,7 @@ class Op(C.Structure):
                 ('bias_per_frame', C.c_int32), ('aux_buf', C.c_int32), ('nterms', C.c_int32),
                 ('term_buf', C.c_int32 * 4), ('term_coff', C.c_int32 * 4), ('term_shift', C.c_int32 * 4),
                 ('w_off2', C.c_int64), ('b_off2', C.c_int64), ('w_off3', C.c_int64),
-                ('flags', C.c_int32), ('reserved', C.c_int32)]
+                ('flags', C.c_int32), ('mode', C.c_int32)]
 
 
 class HeadLayout(C.Structure):
@@ -37,7 +39,8 @@ class HeadLayout(C.Structure):
 EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy', 'acrmi_load_weights',
            'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
-           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans']
+           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
+           'acrmi_set_option', 'acrmi_point_heads']
 
 _lib = None
 
@@ -84,6 +87,8 @@ def lib():
     L.acrmi_tune.argtypes = [i32, i32]
     L.acrmi_preprocess.argtypes = [u8p, i32, i32, i32, u8p, vp, vp]
     L.acrmi_cam_trans.argtypes = [f32p, f32p, i32, C.c_float, C.c_float, f32p, vp]
+    L.acrmi_set_option.argtypes = [vp, i32, i32]
+    L.acrmi_point_heads.argtypes = [vp, i32, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr'):

@@ -23,6 +23,8 @@ struct acrmi_ctx {
   int max_batch = 0;
   float* att_ws = nullptr;      // attention-pool workspace
   size_t att_ws_floats = 0;
+  int* picks = nullptr;         // point heads: decoded centers per frame [max_batch,4]
+  bool point_heads = false;     // ACRMI_OPT_POINT_HEADS
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
   std::vector<float*> mano_allocs;
@@ -74,6 +76,8 @@ static void free_program(acrmi_ctx* c) {
   c->ops.clear();
   if (c->att_ws) (void)hipFree(c->att_ws);
   c->att_ws = nullptr;
+  if (c->picks) (void)hipFree(c->picks);
+  c->picks = nullptr;
   c->have_program = false;
 }
 
@@ -178,6 +182,22 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       HIPCHK(c, launch_coordfill(ptr(op.out_buf), c->max_batch, d.h, d.w, d.cs, op.out_coff, s));
       return ACRMI_OK;
     }
+    case ACRMI_OP_POINTHEADS: {
+      const acrmi_head_layout& h = c->heads;
+      const int side = op.flags & 1;
+      PointArgs p{};
+      p.x34 = ptr(op.in_buf); p.x_cs = desc(op.in_buf).cs;
+      p.center[0] = ptr(h.center_buf[0]); p.center[1] = ptr(h.center_buf[1]); p.center_cs = desc(h.center_buf[0]).cs;
+      p.w = c->weights + op.w_off;
+      p.mix_w = c->weights + op.w_off2;
+      p.bias = ptr(op.aux_buf); p.bias_stride = desc(op.aux_buf).cs;
+      p.p109 = ptr(op.res_buf); p.p109_cs = desc(op.res_buf).cs;
+      p.prior = ptr(h.prior_buf[side]); p.prior_cs = desc(h.prior_buf[side]).cs;
+      p.final_ = ptr(op.out_buf); p.final_cs = desc(op.out_buf).cs;
+      p.picks = c->picks; p.side = side; p.B = B;
+      HIPCHK(c, launch_point_heads(p, s));
+      return ACRMI_OK;
+    }
     default:
       return fail(c, ACRMI_EINVAL, "unknown op kind %d", op.kind);
   }
@@ -210,9 +230,18 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       if (id >= n_bufs) return fail(c, ACRMI_EINVAL, "op %d references buffer %d of %d", i, id, n_bufs);
     if (op.kind == ACRMI_OP_CONV && (op.in_coff % 4 || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2))
       return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
+    if (op.kind == ACRMI_OP_POINTHEADS) {
+      const bool ok = op.in_buf >= 0 && op.res_buf >= 0 && op.out_buf >= 0 && op.aux_buf >= 0 &&
+                      bufs[op.in_buf].h == 128 && bufs[op.in_buf].w == 128 && bufs[op.in_buf].cs == 36 &&
+                      bufs[op.res_buf].h == 64 && bufs[op.out_buf].h == 64 && bufs[op.res_buf].cs >= 109 &&
+                      bufs[op.out_buf].cs >= 109 && bufs[op.aux_buf].cs >= 109 && op.mode == ACRMI_MODE_POINT;
+      if (!ok) return fail(c, ACRMI_EINVAL, "op %d: unsupported point-heads geometry", i);
+    }
+    if (op.mode < ACRMI_MODE_BOTH || op.mode > ACRMI_MODE_POINT) return fail(c, ACRMI_EINVAL, "op %d: bad mode", i);
   }
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
+  HIPCHK(c, hipMalloc(&c->picks, (size_t)max_batch * 4 * sizeof(int)));
   c->have_program = true;
   // init-time ops (constants that live in persistent buffers)
   for (const acrmi_op& op : c->ops)
@@ -255,7 +284,12 @@ int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float
   return ACRMI_OK;
 }
 
-int acrmi_backbone_heads(acrmi_ctx* c, const uint8_t* img, int B, void* stream) {
+// ops of the other head variant are skipped
+static inline bool op_active(const acrmi_op& op, bool point) {
+  return op.kind != ACRMI_OP_COORDFILL && op.mode != (point ? ACRMI_MODE_DENSE : ACRMI_MODE_POINT);
+}
+
+static int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point) {
   if (!c || !img) return fail(c, ACRMI_EINVAL, "acrmi_backbone_heads: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_heads: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
@@ -263,7 +297,7 @@ int acrmi_backbone_heads(acrmi_ctx* c, const uint8_t* img, int B, void* stream) 
   int i = 0;
   for (const acrmi_op& op : c->ops) {
     ++i;
-    if (op.kind == ACRMI_OP_COORDFILL) continue;
+    if (!op_active(op, point)) continue;
     if (dbg_sync) fprintf(stderr, "[acrmi] op %d kind %d B %d\n", i - 1, (int)op.kind, B), fflush(stderr);
     int r = run_op(c, op, img, B, (hipStream_t)stream);
     if (r) return r;
@@ -272,19 +306,53 @@ int acrmi_backbone_heads(acrmi_ctx* c, const uint8_t* img, int B, void* stream) 
   return ACRMI_OK;
 }
 
+int acrmi_backbone_heads(acrmi_ctx* c, const uint8_t* img, int B, void* stream) {
+  return run_program(c, img, B, stream, /*point=*/false);   // the dense maps are this call's result
+}
+
+int acrmi_point_heads(acrmi_ctx* c, int B, void* stream) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_point_heads: ctx is NULL");
+  if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_point_heads: no program");
+  if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  int n = 0;
+  for (const acrmi_op& op : c->ops)
+    if (op.kind == ACRMI_OP_POINTHEADS) {
+      int r = run_op(c, op, nullptr, B, (hipStream_t)stream);
+      if (r) return r;
+      ++n;
+    }
+  if (!n) return fail(c, ACRMI_EINVAL, "acrmi_point_heads: the program has no point-heads ops");
+  return ACRMI_OK;
+}
+
+int acrmi_set_option(acrmi_ctx* c, int option, int value) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_set_option: ctx is NULL");
+  if (option == ACRMI_OPT_POINT_HEADS) {
+    if (value && c->have_program) {
+      bool any = false;
+      for (const acrmi_op& op : c->ops) any |= op.kind == ACRMI_OP_POINTHEADS;
+      if (!any) return fail(c, ACRMI_EINVAL, "acrmi_set_option: the program has no point-heads ops");
+    }
+    c->point_heads = value != 0;
+    return ACRMI_OK;
+  }
+  return fail(c, ACRMI_EINVAL, "acrmi_set_option: unknown option %d", option);
+}
+
 int acrmi_profile_ops(acrmi_ctx* c, const uint8_t* img, int B, float* ms_out, int n_ms, void* stream) {
   if (!c || !img || !ms_out) return fail(c, ACRMI_EINVAL, "acrmi_profile_ops: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "no program");
   const int n = (int)c->ops.size();
   if (n_ms < n) return fail(c, ACRMI_EINVAL, "ms_out too small (%d < %d)", n_ms, n);
   hipStream_t s = (hipStream_t)stream;
-  int r = acrmi_backbone_heads(c, img, B, stream);
+  const bool point = c->point_heads;
+  int r = run_program(c, img, B, stream, point);
   if (r) return r;
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
   HIPCHK(c, hipEventRecord(ev[0], s));
   for (int i = 0; i < n; ++i) {
-    if (c->ops[i].kind != ACRMI_OP_COORDFILL) {
+    if (op_active(c->ops[i], point)) {
       r = run_op(c, c->ops[i], img, B, s);
       if (r) return r;
     }
@@ -358,7 +426,7 @@ int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets,
                   float* joints, float* verts_camed, float* pj2d, float* pj2d_org, void* stream) {
   if (!c || !slots || !verts || !joints) return fail(c, ACRMI_EINVAL, "acrmi_forward: bad arguments");
   if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_forward: MANO tables not loaded");
-  int r = acrmi_backbone_heads(c, img, B, stream);
+  int r = run_program(c, img, B, stream, c->point_heads);
   if (r) return r;
   r = acrmi_decode(c, B, slots, stream);
   if (r) return r;

@@ -97,7 +97,10 @@ struct NoHook {
 
 // hook(item, item_seq, is_last_chunk) runs on the loader waves after chunk k's patch is written to LDS and
 // before barrier k (used to pre-stage the item's residual tile next to its last chunk).
-template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook>
+// PREP_SLACK: compute the next item's geometry in the slack before the barrier (direct kernels: their compute waves
+// reach the barrier late) instead of right before its first request (Winograd kernel: there the loader is what the
+// barrier waits for, and anything ahead of it delays every wave).
+template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook, bool PREP_SLACK = true>
 __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk, float* lds, int ltid, int ktotal,
                                           int cin_pad, Hook hook = Hook()) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4, PAD = KS / 2;
@@ -154,7 +157,8 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       }
     }
   };
-  auto request = [&](Stage& st, bool valid) {   // prepare() for this position has run
+  auto request = [&](Stage& st, bool valid) {   // PREP_SLACK: prepare() for this position has run
+    if constexpr (!PREP_SLACK) prepare(valid);
     st.pixok = pixok_n;
     st.c = cn0 + c4off;
     const int cc = st.c < a.Cin ? st.c : 0;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       }
     }
     hook(w, k / nchunks_l, c0 + CK >= cin_pad);
-    prepare(prep);
+    if constexpr (PREP_SLACK) prepare(prep);
     // barrier k: buffer k&1 is full; the compute waves finished reading it two chunks ago
     __syncthreads();
     c0 += CK;
@@ -200,9 +204,9 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   Stage s0, s1;
   if constexpr (RUN_AHEAD) {
     if (ktotal > 0) {
-      prepare(true);
+      if constexpr (PREP_SLACK) prepare(true);
       request(s0, true);
-      prepare(ktotal > 1);
+      if constexpr (PREP_SLACK) prepare(ktotal > 1);
       for (int k = 0; k < ktotal; k += 2) {
         request(s1, k + 1 < ktotal);
         write(s0, k, k + 2 < ktotal);
@@ -213,7 +217,7 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       }
     }
   } else {
-    prepare(ktotal > 0);
+    if constexpr (PREP_SLACK) prepare(ktotal > 0);
     for (int k = 0; k < ktotal; ++k) {
       request(s0, true);
       write(s0, k, k + 1 < ktotal);

@@ -236,28 +236,33 @@ __device__ inline void rot6d_to_aa(const float* x6, float* aa) {
   }
 }
 
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  __shared__ float cmap[2][64 * 64];
-  __shared__ float bestv[2][4];
-  __shared__ int besti[2][4];
-  __shared__ int s_flat[2], s_flag[2], s_prior;
-  __shared__ float s_score[2];
-  __shared__ float pred[2][112];
+// NMS + arg-max + threshold of both center maps of frame b (acr/result_parser.py:218-249) and the cross-hand prior
+// gate (:42-47, :131-145).  Called by all 256 threads of a workgroup; the result is in *pk after the last barrier.
+struct CenterPick {
+  int flat[2], flag[2], prior;
+  float score[2];
+};
+struct PickScratch {
+  float cmap[2][64 * 64];
+  float bestv[2][4];
+  int besti[2][4];
+};
+__device__ inline void pick_centers(const float* const* center, int center_cs, int b, PickScratch& sc, CenterPick& pk) {
+  const int tid = threadIdx.x;
   for (int h = 0; h < 2; ++h)
-    for (int i = tid; i < 4096; i += 256) cmap[h][i] = a.center[h][((size_t)b * 4096 + i) * a.center_cs];
+    for (int i = tid; i < 4096; i += 256) sc.cmap[h][i] = center[h][((size_t)b * 4096 + i) * center_cs];
   __syncthreads();
   for (int h = 0; h < 2; ++h) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < 4096; i += 256) {
       const int y = i >> 6, x = i & 63;
-      const float v = cmap[h][i];
+      const float v = sc.cmap[h][i];
       float m = v;
       for (int dy = -2; dy <= 2; ++dy)
         for (int dx = -2; dx <= 2; ++dx) {
           const int yy = y + dy, xx = x + dx;
-          if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) m = fmaxf(m, cmap[h][yy * 64 + xx]);
+          if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) m = fmaxf(m, sc.cmap[h][yy * 64 + xx]);
         }
       const float det = (m == v) ? v : v * 0.f;      // x * (maxpool(x) == x)  (acr/result_parser.py:245-249)
       if (det > bv || (det == bv && i < bi)) { bv = det; bi = i; }
@@ -267,28 +272,40 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
       const int oi = __shfl_down(bi, off, 64);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if ((tid & 63) == 0) { bestv[h][tid >> 6] = bv; besti[h][tid >> 6] = bi; }
+    if ((tid & 63) == 0) { sc.bestv[h][tid >> 6] = bv; sc.besti[h][tid >> 6] = bi; }
   }
   __syncthreads();
   if (tid == 0) {
     for (int h = 0; h < 2; ++h) {
-      float bv = bestv[h][0];
-      int bi = besti[h][0];
+      float bv = sc.bestv[h][0];
+      int bi = sc.besti[h][0];
       for (int w = 1; w < 4; ++w)
-        if (bestv[h][w] > bv || (bestv[h][w] == bv && besti[h][w] < bi)) { bv = bestv[h][w]; bi = besti[h][w]; }
-      s_flag[h] = bv > 0.35f;                         // strict (acr/result_parser.py:241)
-      s_flat[h] = s_flag[h] ? bi : 0;                 // placeholder samples pixel 0 (:106-120)
-      s_score[h] = bv;
+        if (sc.bestv[h][w] > bv || (sc.bestv[h][w] == bv && sc.besti[h][w] < bi)) { bv = sc.bestv[h][w]; bi = sc.besti[h][w]; }
+      pk.flag[h] = bv > 0.35f;                        // strict (acr/result_parser.py:241)
+      pk.flat[h] = pk.flag[h] ? bi : 0;               // placeholder samples pixel 0 (:106-120)
+      pk.score[h] = bv;
     }
-    int use = s_flag[0] && s_flag[1];
+    int use = pk.flag[0] && pk.flag[1];
     if (use) {                                        // determine_coeff (:42-47): > 32 px apart -> no prior
-      const float dy = (float)(s_flat[0] >> 6) - (float)(s_flat[1] >> 6);
-      const float dx = (float)(s_flat[0] & 63) - (float)(s_flat[1] & 63);
+      const float dy = (float)(pk.flat[0] >> 6) - (float)(pk.flat[1] >> 6);
+      const float dx = (float)(pk.flat[0] & 63) - (float)(pk.flat[1] & 63);
       if (sqrtf(dy * dy + dx * dx) > 32.f) use = 0;
     }
-    s_prior = use;
+    pk.prior = use;
   }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ PickScratch sc;
+  __shared__ CenterPick pk;
+  __shared__ float pred[2][112];
+  pick_centers(a.center, a.center_cs, b, sc, pk);
+  const int* s_flat = pk.flat;
+  const int* s_flag = pk.flag;
+  const float* s_score = pk.score;
+  const int s_prior = pk.prior;
   if (tid < 218) {
     const int h = tid / 109, c = tid % 109;
     float v = a.params[h][((size_t)b * 4096 + s_flat[h]) * a.params_cs + c];
@@ -322,6 +339,239 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
 }
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Point heads.  ResultParser reads the 109-ch params map at ONE pixel per hand (its own center,
+// acr/result_parser.py:49-57,105,115) and the 106-ch prior map at ONE pixel (the other hand's center, :141-145), so
+// after the center heads have run the other six head towers (acr/model.py:71-99,288-313: 3x3 s2 entry conv, two
+// BasicBlocks, 1x1 exit) only need their 9x9 receptive field around that pixel: per (frame, side) three "tower
+// points" (params @ own center, cam @ own center, prior @ other center) of ~4.7 MMAC each instead of three 64x64
+// towers of 1.2 GMAC.  Zero padding is the map's, not the window's: every intermediate position outside the 64x64
+// map is forced to 0 exactly as the dense convolution sees it.
+//   pick   : centers of both hands per frame -> picks[b] = {flat_l, flat_r, prior gate, 0}
+//   tower  : one workgroup (8 waves) per tower point, fp32 FMA (M is 81..1 pixels - far too small for MFMA tiles):
+//            lane <-> output channel, wave <-> pixels; activations are LDS broadcasts, weights coalesced float4
+//            rows [tap][cin/4][cout][4] from L2; window buffers never leave LDS
+//   mix    : cam scale 1.1**x, 109x109 mix conv + per-frame pare bias (acr/model.py:95-96,160-164) at the pixel
+// The results are written into the pixels of the dense maps that acrmi_decode reads, so decode is unchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_pick_kernel(const PointArgs a) {
+  __shared__ PickScratch sc;
+  __shared__ CenterPick pk;
+  pick_centers(a.center, a.center_cs, blockIdx.x, sc, pk);
+  if (threadIdx.x == 0) {
+    int* o = a.picks + blockIdx.x * 4;
+    o[0] = pk.flat[0]; o[1] = pk.flat[1]; o[2] = pk.prior; o[3] = 0;
+  }
+}
+
+constexpr int TP_WAVES = 8;
+constexpr int TP_XW = 19;                      // input window of the stride-2 entry conv for a 9x9 tower window
+constexpr int TP_XC = 36;                      // 34 channels + 2 zero
+constexpr int TP_XIN = TP_XW * TP_XW * TP_XC;  // floats
+constexpr int TP_LDS_FLOATS = TP_XIN + 81 * 64;
+
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b, float acc) {
+  acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc);
+  acc = fmaf(a[2], b[2], acc); return fmaf(a[3], b[3], acc);
+}
+
+// 3x3 conv 64->64 + bias [+ residual] + ReLU on an NIN x NIN window in LDS -> (NIN-2)^2 window, positions outside
+// the 64x64 map zeroed.  (oy0, ox0) = map coordinates of the output window's origin.
+template <int NIN, int NRES>
+__device__ __forceinline__ void tp_conv64(const float* in, float* out, const float* __restrict__ wgt,
+                                          const float* __restrict__ bias, const float* res, int oy0, int ox0, int co,
+                                          int wv, float* red) {
+  constexpr int NOUT = NIN - 2, NP = NOUT * NOUT;
+  const f32x4* W = reinterpret_cast<const f32x4*>(wgt);   // [(tap*16 + c4)*64 + co]
+  float v0 = 0.f;   // value of output pixel (this wave's first), NP == 1 path
+  if constexpr (NP == 1) {
+    // one pixel: split K over the waves by tap (wave 0 also takes tap 8), reduce through LDS
+    float acc = 0.f;
+    for (int tap = wv; tap < 9; tap += TP_WAVES) {
+      const float* src = in + ((tap / 3) * NIN + tap % 3) * 64;
+      f32x4 w[16];
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) w[c4] = W[(tap * 16 + c4) * 64 + co];
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) acc = dot4(w[c4], *reinterpret_cast<const f32x4*>(src + c4 * 4), acc);
+    }
+    red[wv * 64 + co] = acc;
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int k = 0; k < TP_WAVES; ++k) v0 += red[k * 64 + co];
+      float v = v0 + bias[co];
+      if constexpr (NRES > 0) v += res[((NRES / 2) * NRES + NRES / 2) * 64 + co];
+      out[co] = fmaxf(v, 0.f);     // the center pixel is always inside the map
+    }
+  } else {
+    constexpr int PER = (NP + TP_WAVES - 1) / TP_WAVES;
+    float acc[PER];
+    int base[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = wv + TP_WAVES * i < NP ? wv + TP_WAVES * i : NP - 1;
+      base[i] = ((p / NOUT) * NIN + p % NOUT) * 64;
+      acc[i] = 0.f;
+    }
+    constexpr int U = 4, G = 9 * 16 / U;       // weight rows per group, groups
+    f32x4 wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wn[u] = W[u * 64 + co];
+    for (int g = 0; g < G; ++g) {
+      f32x4 wc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) wc[u] = wn[u];
+      const int gn = g + 1 < G ? g + 1 : g;    // (unconditional prefetch: the last group re-reads itself)
+#pragma unroll
+      for (int u = 0; u < U; ++u) wn[u] = W[(gn * U + u) * 64 + co];
+      const int tap = g / (16 / U), c4 = (g % (16 / U)) * U;
+      const int off = ((tap / 3) * NIN + tap % 3) * 64 + c4 * 4;
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          acc[i] = dot4(wc[u], *reinterpret_cast<const f32x4*>(in + base[i] + off + u * 4), acc[i]);
+    }
+    const float bv = bias[co];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = wv + TP_WAVES * i;
+      if (p < NP) {
+        const int oy = p / NOUT, ox = p % NOUT;
+        float v = acc[i] + bv;
+        if constexpr (NRES > 0) v += res[((oy + (NRES - NOUT) / 2) * NRES + ox + (NRES - NOUT) / 2) * 64 + co];
+        const bool inside = (unsigned)(oy0 + oy) < 64u && (unsigned)(ox0 + ox) < 64u;
+        out[p * 64 + co] = inside ? fmaxf(v, 0.f) : 0.f;
+      }
+    }
+  }
+  (void)v0;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TP_WAVES * 64) void tower_point_kernel(const PointArgs a) {
+  extern __shared__ float tp_lds[];
+  const int b = blockIdx.x / 3, t = blockIdx.x % 3, tid = threadIdx.x;
+  const int co = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int* pk = a.picks + b * 4;
+  if (t == 2 && !pk[2]) return;                  // the prior is only read when the gate is open
+  const int flat = t == 2 ? pk[1 - a.side] : pk[a.side];
+  const int cy = flat >> 6, cx = flat & 63;
+  float* xin = tp_lds;                           // [19*19][36], dead after the entry conv
+  float* t0 = tp_lds + TP_XIN;                   // [9*9][64]   tower input (block 0 residual)
+  float* fa = xin;                               // [7*7][64]
+  float* fb = fa + 49 * 64;                      // [5*5][64]   (block 1 residual)
+  float* fc = fb + 25 * 64;                      // [3*3][64]
+  float* fd = fc + 9 * 64;                       // [64]
+  float* red = fd + 64;                          // [8][64]
+  const float* wt = a.w + (size_t)t * TP_TOWER_FLOATS;
+  // ---- x34 window: rows/cols 2*(c-4)-1 .. 2*(c+4)+1 ----
+  const float* xb = a.x34 + (size_t)b * 128 * 128 * a.x_cs;
+  for (int i = tid; i < TP_XW * TP_XW * 9; i += TP_WAVES * 64) {
+    const int pix = i / 9, c4 = i - pix * 9;
+    const int iy = 2 * (cy - 4) - 1 + pix / TP_XW, ix = 2 * (cx - 4) - 1 + pix % TP_XW;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < 128u && (unsigned)ix < 128u) {
+      v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * 128 + ix) * a.x_cs + c4 * 4);
+      if (c4 == 8) { v[2] = 0.f; v[3] = 0.f; }
+    }
+    *reinterpret_cast<f32x4*>(xin + pix * TP_XC + c4 * 4) = v;
+  }
+  __syncthreads();
+  // ---- entry: 3x3 stride 2, 34 -> 64, ReLU (acr/model.py:300-303) on the 9x9 window ----
+  {
+    constexpr int PER = (81 + TP_WAVES - 1) / TP_WAVES;
+    const f32x4* W = reinterpret_cast<const f32x4*>(wt);   // [(tap*9 + c4)*64 + co]
+    float acc[PER];
+    int base[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = wv + TP_WAVES * i < 81 ? wv + TP_WAVES * i : 80;
+      base[i] = ((2 * (p / 9)) * TP_XW + 2 * (p % 9)) * TP_XC;
+      acc[i] = 0.f;
+    }
+    constexpr int U = 3, G = 81 / U;
+    f32x4 wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wn[u] = W[u * 64 + co];
+    for (int g = 0; g < G; ++g) {
+      f32x4 wc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) wc[u] = wn[u];
+      const int gn = g + 1 < G ? g + 1 : g;
+#pragma unroll
+      for (int u = 0; u < U; ++u) wn[u] = W[(gn * U + u) * 64 + co];
+      const int tap = g / 3, c4 = (g % 3) * U;
+      const int off = ((tap / 3) * TP_XW + tap % 3) * TP_XC + c4 * 4;
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          acc[i] = dot4(wc[u], *reinterpret_cast<const f32x4*>(xin + base[i] + off + u * 4), acc[i]);
+    }
+    const float bv = wt[TP_ENTRY_W + co];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = wv + TP_WAVES * i;
+      if (p < 81) {
+        const bool inside = (unsigned)(cy - 4 + p / 9) < 64u && (unsigned)(cx - 4 + p % 9) < 64u;
+        t0[p * 64 + co] = inside ? fmaxf(acc[i] + bv, 0.f) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- two BasicBlocks (acr/model.py:483-499): relu(bn(conv)) -> bn(conv) + x -> relu ----
+  const float* wc = wt + TP_ENTRY_W + 64;
+  constexpr int CS = TP_CONV_W + 64;
+  tp_conv64<9, 0>(t0, fa, wc, wc + TP_CONV_W, nullptr, cy - 3, cx - 3, co, wv, red);
+  tp_conv64<7, 9>(fa, fb, wc + CS, wc + CS + TP_CONV_W, t0, cy - 2, cx - 2, co, wv, red);
+  tp_conv64<5, 0>(fb, fc, wc + 2 * CS, wc + 2 * CS + TP_CONV_W, nullptr, cy - 1, cx - 1, co, wv, red);
+  tp_conv64<3, 5>(fc, fd, wc + 3 * CS, wc + 3 * CS + TP_CONV_W, fb, cy, cx, co, wv, red);
+  // ---- 1x1 exit (acr/model.py:305-311) -> the pixel of the dense map ----
+  const float* we = wc + 4 * CS;                 // [64][112], bias [112]
+  const int nout = t == 1 ? 3 : 106;
+  if (tid < nout) {
+    float s = we[64 * TP_EXIT_N + tid];
+#pragma unroll 8
+    for (int ci = 0; ci < 64; ++ci) s = fmaf(we[ci * TP_EXIT_N + tid], fd[ci], s);
+    if (t == 2) a.prior[((size_t)b * 4096 + flat) * a.prior_cs + tid] = s;
+    else a.p109[((size_t)b * 4096 + flat) * a.p109_cs + (t == 0 ? 3 : 0) + tid] = s;
+  }
+}
+
+__global__ __launch_bounds__(128) void point_mix_kernel(const PointArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int flat = a.picks[b * 4 + a.side];
+  __shared__ float p[112];
+  if (tid < 109) {
+    float v = a.p109[((size_t)b * 4096 + flat) * a.p109_cs + tid];
+    p[tid] = tid == 0 ? powf(1.1f, v) : v;         // cam scale (acr/model.py:95-96)
+  }
+  __syncthreads();
+  if (tid < 109) {
+    float s = a.bias[(size_t)b * a.bias_stride + tid];
+    for (int ci = 0; ci < 109; ++ci) s = fmaf(a.mix_w[ci * TP_EXIT_N + tid], p[ci], s);
+    a.final_[((size_t)b * 4096 + flat) * a.final_cs + tid] = s;
+  }
+}
+
+hipError_t launch_point_heads(const PointArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int LDS_BYTES = TP_LDS_FLOATS * (int)sizeof(float);
+  static_assert(TP_XIN >= (49 + 25 + 9 + 1 + TP_WAVES) * 64, "window buffers alias the dead x34 window");
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_point_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(center_pick_kernel, dim3(a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(tower_point_kernel, dim3(a.B * 3), dim3(TP_WAVES * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(point_mix_kernel, dim3(a.B), dim3(128), 0, s, a);
   return hipGetLastError();
 }
 

@@ -77,6 +77,27 @@ struct DecodeArgs {
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
 
+// Point heads: the six non-center head towers evaluated only at the pixels the decode reads (heads.hip).
+// Per tower (floats): entry W [9 taps][9 cin/4][64 cout][4] + b[64]; 4 x (conv W [9][16][64][4] + b[64]);
+// exit W [64][112] + b[112].  Three towers per side in the order params (k=1), cam (k=3), prior (k=4).
+constexpr int TP_ENTRY_W = 9 * 9 * 64 * 4;
+constexpr int TP_CONV_W = 9 * 16 * 64 * 4;
+constexpr int TP_EXIT_N = 112;
+constexpr int TP_TOWER_FLOATS = TP_ENTRY_W + 64 + 4 * (TP_CONV_W + 64) + 64 * TP_EXIT_N + TP_EXIT_N;
+struct PointArgs {
+  const float* x34; int x_cs;              // [B,128,128,x_cs] backbone features + coord maps (34 channels)
+  const float* center[2]; int center_cs;   // [B,64,64,center_cs] channel 0
+  const float* w;                          // 3 x TP_TOWER_FLOATS (this side)
+  const float* mix_w;                      // [109 cin][TP_EXIT_N] mix conv (cam3 columns merged)
+  const float* bias; int bias_stride;      // per-frame pare bias rows
+  float* p109; int p109_cs;                // [B,64,64,cs] cam(3) | params(106) before the mix
+  float* prior; int prior_cs;              // [B,64,64,cs] 106-ch prior map
+  float* final_; int final_cs;             // [B,64,64,cs] 109-ch params map after the mix
+  int* picks;                              // [B,4] workspace: flat_l, flat_r, prior gate
+  int side, B;
+};
+hipError_t launch_point_heads(const PointArgs& a, hipStream_t s);
+
 struct ManoTables {   // device pointers
   const float* v_template;   // [778*3]
   const float* shapedirs_t;  // [10][2334]   (transposed for coalesced reads)

@@ -27,6 +27,7 @@ class Engine(object):
         self.max_batch = 0
         self.program = None
         self.have_mano = False
+        self.point_heads = False
 
     def close(self):
         if self.ctx:
@@ -57,6 +58,17 @@ class Engine(object):
             _lib.check(self.L.acrmi_set_program(self.ctx, bufs, len(bufs), ops, len(ops), C.byref(prog['heads']),
                                                 max_batch), self.ctx)
         self.max_batch = max_batch
+
+    def set_point_heads(self, on):
+        """ACRMI_OPT_POINT_HEADS: `forward` evaluates the params/cam/prior head towers and the mix conv only at the
+        pixels ResultParser samples (acr/result_parser.py:49-57,141-145).  Same slots / vertices up to fp32
+        round-off; `head_maps` params/prior maps are then only valid after `backbone_heads` (always dense)."""
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_POINT_HEADS, int(bool(on))), self.ctx)
+        self.point_heads = bool(on)
+
+    def run_point_heads(self, B):
+        """Re-evaluates the point heads on the resident buffers for the current center maps (acrmi_point_heads)."""
+        _lib.check(self.L.acrmi_point_heads(self.ctx, B, _stream(self.device)), self.ctx)
 
     def ensure_batch(self, B):
         if self.program is None:

@@ -166,7 +166,23 @@ class Program(object):
         for k, v in kw.items():
             setattr(op, k, v)
         self.ops.append(op)
-        self.op_info.append({'name': name, 'flops': float(flops), 'kind': int(op.kind)})
+        self.op_info.append({'name': name, 'flops': float(flops), 'kind': int(op.kind), 'mode': int(op.mode)})
+        return op
+
+    def set_mode(self, mode, first):
+        """Tags ops[first:] with a head-program variant (_lib.MODE_*)."""
+        for op, info in zip(self.ops[first:], self.op_info[first:]):
+            op.mode = info['mode'] = mode
+
+    def clone_op(self, i, name, flops_scale, **kw):
+        """Copy of op i (same packed weights / buffers) with some fields changed."""
+        op = _lib.Op.from_buffer_copy(bytes(self.ops[i]))
+        for k, v in kw.items():
+            setattr(op, k, v)
+        self.ops.append(op)
+        info = dict(self.op_info[i])
+        info.update(name=name, flops=info['flops'] * flops_scale, mode=int(op.mode))
+        self.op_info.append(info)
         return op
 
     def conv(self, name, src, wb_list, k, stride, relu, out=None, out_c=None, in_coff=0, out_coff=0, res=None,
@@ -269,8 +285,34 @@ class Program(object):
         return outs
 
 
-def lower(sd, check=True):
-    """state dict -> dict(blob, bufs, ops, heads, op_info).  See module docstring."""
+def point_tower(P, side, k):
+    """Head tower (side, k) (acr/model.py:288-313) in the layout of tower_point_kernel (csrc/kernels.h TP_*):
+    entry W [tap][cin/4][cout][4] (cin 34 -> 36) + b, 4 x (3x3 W [tap][16][64][4] + b), exit W [64][112] + b[112]."""
+    def rows(w, cpad):
+        co, ci = w.shape[:2]
+        wp = np.zeros((co, cpad, 3, 3))
+        wp[:, :ci] = w
+        return wp.reshape(co, cpad // 4, 4, 9).transpose(3, 1, 0, 2).reshape(-1)
+    pre = '%s_final_layers.%d' % (side, k)
+    w, b = P.folded(pre + '.0.0', pre + '.0.1')
+    parts = [rows(w, 36), b]
+    for blk in range(2):
+        for c in (1, 2):
+            w, b = P.folded(pre + '.1.%d.0.conv%d' % (blk, c), pre + '.1.%d.0.bn%d' % (blk, c))
+            parts += [rows(w, 64), b]
+    w, b = P.folded(pre + '.2')
+    we = np.zeros((64, 112))
+    we[:, :w.shape[0]] = w[:, :, 0, 0].T
+    be = np.zeros(112)
+    be[:w.shape[0]] = b
+    out = np.concatenate([np.asarray(x, np.float64).reshape(-1) for x in parts + [we, be]])
+    assert out.size == 9 * 9 * 64 * 4 + 64 + 4 * (9 * 16 * 64 * 4 + 64) + 64 * 112 + 112
+    return out
+
+
+def lower(sd, check=True, point_heads=True):
+    """state dict -> dict(blob, bufs, ops, heads, op_info).  See module docstring.
+    point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT)."""
     sd = strip_prefix(sd)
     if check:
         check_state_dict(sd)
@@ -320,18 +362,31 @@ def lower(sd, check=True):
     P.conv(g + '.3', s3, [P.folded(g + '.3')], 3, 1, False, out=segm)
     P.release(s3)
     # ---- 8 head towers (acr/model.py:71-92, 288-313), batched as one 34->512 conv + grouped blocks --
-    towers = [(side, k) for side in 'lr' for k in (1, 2, 3, 4)]
+    # The two center towers come first: the point-heads variant runs the same grouped convs with
+    # groups=2 on channels 0..127 and evaluates the other six towers only at the decoded centers (OP_POINTHEADS).
+    towers = [('l', 2), ('r', 2)] + [(side, k) for side in 'lr' for k in (1, 3, 4)]
     w_list = [P.folded('%s_final_layers.%d.0.0' % t, '%s_final_layers.%d.0.1' % t) for t in towers]
     wcat = np.concatenate([w for w, _ in w_list], 0)
     bcat = np.concatenate([bb for _, bb in w_list], 0)
+    n0 = len(P.ops)
     t0 = P.conv('towers.entry', x34, [(wcat, bcat)], 3, 2, True, cin=34)
+    P.set_mode(_lib.MODE_DENSE, n0)
+    if point_heads:
+        n0 = len(P.ops)
+        P.conv('towers.entry.centers', x34, [(wcat[:128], bcat[:128])], 3, 2, True, cin=34, out=t0)
+        P.set_mode(_lib.MODE_POINT, n0)
     for k in range(2):
         c1 = [P.folded('%s_final_layers.%d.1.%d.0.conv1' % (s_, t_, k), '%s_final_layers.%d.1.%d.0.bn1' % (s_, t_, k))
               for s_, t_ in towers]
         c2 = [P.folded('%s_final_layers.%d.1.%d.0.conv2' % (s_, t_, k), '%s_final_layers.%d.1.%d.0.bn2' % (s_, t_, k))
               for s_, t_ in towers]
+        n0 = len(P.ops)
         t1 = P.conv('towers.block%d.conv1' % k, t0, c1, 3, 1, True)
         t2 = P.conv('towers.block%d.conv2' % k, t1, c2, 3, 1, True, res=t0)
+        P.set_mode(_lib.MODE_DENSE, n0)
+        if point_heads:
+            for j in (n0, n0 + 1):
+                P.clone_op(j, P.op_info[j]['name'] + '.centers', 2.0 / len(towers), groups=2, mode=_lib.MODE_POINT)
         P.release(t1, t0)
         t0 = t2
     heads = _lib.HeadLayout()
@@ -343,8 +398,11 @@ def lower(sd, check=True):
         for k, (dst, coff) in ((1, (p109[side], 3)), (2, (center, 0)), (3, (p109[side], 0)), (4, (prior, 0))):
             ti = towers.index((side, k))
             name = '%s_final_layers.%d.2' % (side, k)
+            n0 = len(P.ops)
             P.conv(name, t0, [P.folded(name)], 1, 1, False, out=dst, in_coff=64 * ti, out_coff=coff, cin=64)
-        P._op('%s.cam_pow' % side, 0.0, kind=_lib.OP_POW11, out_buf=p109[side], out_coff=0)
+            if k != 2:
+                P.set_mode(_lib.MODE_DENSE, n0)
+        P._op('%s.cam_pow' % side, 0.0, kind=_lib.OP_POW11, out_buf=p109[side], out_coff=0, mode=_lib.MODE_DENSE)
         heads.center_buf[si], heads.prior_buf[si] = center, prior
     P.release(t0)
     # ---- part branch (acr/model.py:116-166) ---------------------------------------------------------
@@ -360,17 +418,25 @@ def lower(sd, check=True):
         wa = wm[:, :109].copy()
         wa[:, :3] += wm[:, 109:112]                 # cam3 appears twice in the concat (acr/model.py:160-163)
         wp = wm[:, 112:]
-        bias_buf = P.buf(1, 1, 112)
+        bias_buf = P.buf(1, 1, 112, persistent=True)     # one per side: acrmi_point_heads re-reads both
         P._op('%s.parebias' % side, 0.0, kind=_lib.OP_PAREBIAS, in_buf=pooled, out_buf=bias_buf, cin=320, flags=part0,
               w_off=P.blob.add(_np(sd['contact_layers.%d.weight' % lc]).reshape(6, 256, 16)),
               w_off2=P.blob.add(_np(sd['cam_shape_layers.%d.weight' % lc])),
               b_off2=P.blob.add(_np(sd['cam_shape_layers.%d.bias' % lc])),
               w_off3=P.blob.add(wp), b_off=P.blob.add(_np(sd['contact_layers.%d.bias' % mix])))
         final = P.buf(64, 64, 109, persistent=True)
+        n0 = len(P.ops)
         P.conv('contact_layers.%d' % mix, p109[side], [(wa.reshape(109, 109, 1, 1), np.zeros(109))], 1, 1, False,
                out=final, cin=109, bias_buf=bias_buf)
         P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 109 * 218
+        P.set_mode(_lib.MODE_DENSE, n0)
+        if point_heads:
+            mixw = np.zeros((109, 112))
+            mixw[:, :109] = wa.T
+            P._op('%s.point_heads' % side, 0.0, kind=_lib.OP_POINTHEADS, in_buf=x34, res_buf=p109[side], out_buf=final,
+                  aux_buf=bias_buf, flags=si, mode=_lib.MODE_POINT,
+                  w_off=P.blob.add(np.concatenate([point_tower(P, side, k) for k in (1, 3, 4)])),
+                  w_off2=P.blob.add(mixw))
         heads.params_buf[si] = final
-        P.release(bias_buf)
     heads.segm_buf, heads.backbone_buf = segm, x34
     return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info}

@@ -54,6 +54,28 @@ def cpu_baseline(sd, tables, n_frames=16):
                       '1 warm-up + 1 timed pass (%.1f s)' % (n_frames, n_frames, dt)}
 
 
+def point_heads_rate(eng, frames, views, steps, warmup):
+    """Reported NEXT TO the headline, never as it: the same frames -> slots/verts/joints with the
+    params/cam/prior head towers evaluated only at the pixels the decode samples (ACRMI_OPT_POINT_HEADS).  The dense
+    head maps are not produced in this mode, so `value` above stays the full path."""
+    B = frames.shape[0]
+    eng.set_point_heads(True)
+    try:
+        for _ in range(max(1, warmup)):
+            eng.forward(frames, out=views)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward(frames, out=views)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        eng.set_point_heads(False)
+    return {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+            'note': 'head towers at decoded centers only; same slots/verts/joints within fp32 round-off; '
+                    'dense params/prior maps not produced'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -61,6 +83,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='frames per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-point-heads', action='store_true', help='skip the separately reported point-heads variant')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
     args = ap.parse_args()
 
@@ -125,8 +148,8 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         fps = world * B * args.steps / dt
         # per-op HIP-event timing of the same program on the same stream (one extra pass)
-        prof = eng.profile_ops(frames)
         L = pkg('_lib')
+        prof = [p for p in eng.profile_ops(frames) if p.get('mode', 0) != L.MODE_POINT]   # the dense program as timed
         if args.profile_out:
             with open(args.profile_out, 'w') as f:
                 json.dump(prof, f, indent=0)
@@ -164,6 +187,8 @@ def main():
                           'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
                           'gflop_per_frame': GFLOP_PER_FRAME},
                'roofline': roofline}
+        if world == 1 and not args.no_point_heads:
+            out['point_heads'] = point_heads_rate(eng, frames, views, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, tables)
         line = json.dumps(out)

@@ -53,7 +53,19 @@ enum {
   ACRMI_OP_POW11 = 5,    /* ch0 := 1.1 ** ch0 (acr/model.py:95-96)                            */
   ACRMI_OP_ATTPOOL = 6,  /* softmax-over-pixels weighted feature pooling (acr/model.py:103-113) */
   ACRMI_OP_PAREBIAS = 7, /* LocallyConnected2d + Linear + mix-conv pare bias (acr/model.py:145-164) */
-  ACRMI_OP_COORDFILL = 8 /* init-time: write coord maps into 2 channels (acr/model.py:340-369) */
+  ACRMI_OP_COORDFILL = 8, /* init-time: write coord maps into 2 channels (acr/model.py:340-369) */
+  ACRMI_OP_POINTHEADS = 9 /* params/cam/prior head towers + 109x109 mix at the decoded centers only (one op per
+                             side = flags; in = backbone+coord buffer, res = pre-mix 109-ch map, out = params
+                             map, aux = per-frame bias; w_off = 3 packed towers, w_off2 = mix weights);
+                             acr/model.py:71-99,160-164 restricted to the pixels acr/result_parser.py:49-57,
+                             141-145 samples */
+};
+
+/* acrmi_op.mode: which variant of the head program an op belongs to. */
+enum {
+  ACRMI_MODE_BOTH = 0,
+  ACRMI_MODE_DENSE = 1,  /* only when the full head maps are computed (default)            */
+  ACRMI_MODE_POINT = 2   /* only with ACRMI_OPT_POINT_HEADS (acrmi_forward)                */
 };
 
 typedef struct {
@@ -68,8 +80,9 @@ typedef struct {
   int32_t nterms;                         /* FUSESUM */
   int32_t term_buf[4], term_coff[4], term_shift[4];
   int64_t w_off2, b_off2, w_off3;         /* PAREBIAS: linear weights/bias, mix-conv pare columns */
-  int32_t flags;                          /* PAREBIAS: part slice start (0 right / 16 left)  */
-  int32_t reserved;
+  int32_t flags;                          /* CONV: algo (bits 0-1); PAREBIAS: part slice start (0 right /
+                                             16 left); POINTHEADS: side (0 left / 1 right)   */
+  int32_t mode;                           /* ACRMI_MODE_*                                    */
 } acrmi_op;
 
 /* Where the head outputs live (buffer ids of the program), needed by acrmi_decode. */
@@ -180,8 +193,19 @@ int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, co
 int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* stats_ws,
                   float* pooled, void* stream);
 
+/* Options.  ACRMI_OPT_POINT_HEADS (0/1, default 0): acrmi_forward evaluates the params/cam/prior head towers and
+ * the mix conv only at the pixels the decode samples (same slots/vertices within fp32 round-off; the dense
+ * l/r_params_maps and l/r_prior_maps are then NOT produced - acrmi_backbone_heads always computes them). */
+#define ACRMI_OPT_POINT_HEADS 1
+int acrmi_set_option(acrmi_ctx* ctx, int option, int value);
+
+/* Runs only the point-heads ops on the resident buffers of the last acrmi_backbone_heads / acrmi_forward call:
+ * params/cam/prior towers + mix (acr/model.py:71-99,160-164) at the centers of the CURRENT center maps, written
+ * into the pixels of the params/prior maps acrmi_decode samples. */
+int acrmi_point_heads(acrmi_ctx* ctx, int B, void* stream);
+
 /* Profiling aid for bench.py: time every op of the program with hipEvents on `stream`
- * (one untimed warm-up pass first).  ms_out[n_ops]; returns n_ops or <0. */
+ * (one untimed warm-up pass first; ops outside the active head mode report 0).  ms_out[n_ops]; returns n_ops or <0. */
 int acrmi_profile_ops(acrmi_ctx* ctx, const uint8_t* img_dev, int B, float* ms_out, int n_ms, void* stream);
 
 /* Tuning hook for kernel experiments (tools/conv_bench.py): key 0 = force a conv tile config id

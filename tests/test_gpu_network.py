@@ -103,6 +103,79 @@ def test_forward_matches_oracle_and_is_batch_invariant(engine, frames2, oracle_m
             assert np.abs(out2['joints'][b, h].cpu().numpy() - j[0]).max() < 1e-4
 
 
+def _assert_point_matches_dense(pt, dense):
+    L = pkg('_lib')
+    ps, ds = pt['slots'].cpu().numpy(), dense['slots'].cpu().numpy()
+    np.testing.assert_array_equal(ps[..., L.SLOT_FLAG], ds[..., L.SLOT_FLAG])
+    np.testing.assert_array_equal(ps[..., L.SLOT_FLATIND], ds[..., L.SLOT_FLATIND])
+    np.testing.assert_array_equal(ps[..., L.SLOT_SCORE], ds[..., L.SLOT_SCORE])
+    # fp32 FMA chains over the same 5 conv layers in a different summation order (direct vs Winograd/MFMA)
+    np.testing.assert_allclose(ps[..., L.SLOT_PARAMS:L.SLOT_PARAMS + 109], ds[..., L.SLOT_PARAMS:L.SLOT_PARAMS + 109],
+                               rtol=5e-5, atol=5e-5)
+    assert (pt['verts'] - dense['verts']).abs().max().item() < 2e-5
+    assert (pt['joints'] - dense['joints']).abs().max().item() < 2e-5
+
+
+def test_point_heads_match_dense_path_and_reference(engine, frames2):
+    """the params/cam/prior towers + mix conv evaluated only at the pixels the decode samples
+    (acr/result_parser.py:49-57,141-145) give the dense path's slots and meshes, and the reference's."""
+    g = golden('e2e_batch1.npz')
+    x = torch.from_numpy(frames2).cuda()
+    dense = {k: v.clone() for k, v in engine.forward(x).items()}
+    hl = engine.program['heads']
+    for si in range(2):      # whatever the point variant does not write must not be read either
+        engine.buffer(hl.params_buf[si], 2).fill_(float('nan'))
+        engine.buffer(hl.prior_buf[si], 2).fill_(float('nan'))
+    engine.set_point_heads(True)
+    try:
+        pt = {k: v.clone() for k, v in engine.forward(x).items()}
+        torch.cuda.synchronize()
+    finally:
+        engine.set_point_heads(False)
+    assert dense['slots'][..., 0].sum().item() == 4          # both hands of both golden frames: prior gate exercised
+    _assert_point_matches_dense(pt, dense)
+    for b in range(2):
+        assert np.abs(pt['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max() < 1e-4
+        assert np.abs(pt['joints'][b].cpu().numpy() - g['f%d_j3d' % b]).max() < 1e-4
+    again = engine.forward(x)                                # the dense program repairs the poisoned maps
+    assert torch.equal(again['verts'], dense['verts'])
+
+
+def test_point_heads_at_map_borders_and_without_detections(engine, synth_sd):
+    """Placeholder rows sample pixel 0 (acr/result_parser.py:106-120): the 9x9 window then hangs over the map corner,
+    where the dense convolutions see zero padding at every layer.  Also centers forced onto all four borders."""
+    synth = pkg('synth')
+    x = torch.from_numpy(synth.make_frames(2, seed=3, structured=False)).cuda()
+    dense = {k: v.clone() for k, v in engine.forward(x).items()}
+    engine.set_point_heads(True)
+    try:
+        pt = {k: v.clone() for k, v in engine.forward(x).items()}
+    finally:
+        engine.set_point_heads(False)
+    _assert_point_matches_dense(pt, dense)
+    # border centers: plant the peaks in the resident center maps and re-run the point heads on them
+    hl = engine.program['heads']
+    B = engine.backbone_heads(x)
+    spots = [((0, 63), (5, 60)), ((63, 0), (62, 7))]       # (left (y,x), right (y,x)) per frame, <= 32 px apart
+    for b, (l, r) in enumerate(spots):
+        for s, (y, xx) in enumerate((l, r)):
+            cm = engine.buffer(hl.center_buf[s], B, 1)
+            cm[b].fill_(0.0)
+            cm[b, y, xx, 0] = 0.9
+    want = engine.decode(B).clone()
+    for s in range(2):
+        engine.buffer(hl.params_buf[s], B).fill_(float('nan'))
+        engine.buffer(hl.prior_buf[s], B).fill_(float('nan'))
+    engine.run_point_heads(B)
+    got = engine.decode(B)
+    torch.cuda.synchronize()
+    L = pkg('_lib')
+    assert want[..., L.SLOT_FLAG].sum().item() == 4
+    for b, (l, r) in enumerate(spots):
+        assert want[b, 0, L.SLOT_FLATIND].item() == l[0] * 64 + l[1] and want[b, 1, L.SLOT_FLATIND].item() == r[0] * 64 + r[1]
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=5e-5, atol=5e-5)
+
+
 def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
     """BASELINE.json's bench configuration (batch 64, 512x512): size-independent properties of the whole path.
     Frames are independent, so (i) the two golden frames planted anywhere in the batch of 64 reproduce the reference's
@@ -132,6 +205,10 @@ def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
             assert torch.equal(out['slots'][p], small['slots'][b])
             assert np.abs(out['verts'][p].cpu().numpy() - g['f%d_verts' % b]).max() < 1e-4
             assert np.abs(out['joints'][p].cpu().numpy() - g['f%d_j3d' % b]).max() < 1e-4
+    eng.set_point_heads(True)                                # (iv) the point-heads variant agrees on all 128 hands
+    pt = {k: v.clone() for k, v in eng.forward(x).items()}
+    eng.set_point_heads(False)
+    _assert_point_matches_dense(pt, out)
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(1))
     outp = eng.forward(x[perm.cuda()].contiguous())
     torch.cuda.synchronize()

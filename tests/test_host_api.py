@@ -91,7 +91,15 @@ def test_pack_conv_layout_and_bn_folding(synth_sd):
 def test_lowering_accounts_for_every_flop_and_rejects_bad_checkpoints(synth_sd):
     packer = pkg('packer')
     prog = packer.lower({'module.' + k: v for k, v in synth_sd.items()})       # wild.pkl style prefix
-    assert abs(sum(o['flops'] for o in prog['op_info']) / 1e9 - 102.1) < 0.1
+    L = pkg('_lib')
+    dense = [o for o in prog['op_info'] if o['mode'] != L.MODE_POINT]
+    point = [o for o in prog['op_info'] if o['mode'] != L.MODE_DENSE]
+    assert abs(sum(o['flops'] for o in dense) / 1e9 - 102.1) < 0.1
+    # point-heads variant: six of the eight head towers + the mix conv leave the dense op list
+    assert 8.0 < (sum(o['flops'] for o in dense) - sum(o['flops'] for o in point)) / 1e9 < 10.5
+    assert [o['name'] for o in point if o['kind'] == L.OP_POINTHEADS] == ['l.point_heads', 'r.point_heads']
+    assert all(op.mode == info['mode'] for op, info in zip(prog['ops'], prog['op_info']))
+    assert len(packer.lower(synth_sd, point_heads=False)['ops']) == len(dense)
     assert len(prog['ops']) < 400 and prog['blob'].dtype == np.float32
     bad = dict(synth_sd)
     del bad['backbone.stage3.1.branches.2.3.bn2.running_var']
