@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, 'libacrmi.so')
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS = range(1, 10)
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
-OPT_POINT_HEADS = 1
+OPT_POINT_HEADS, OPT_LANES = 1, 2
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
 E_INVAL, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4

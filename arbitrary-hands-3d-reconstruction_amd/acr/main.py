@@ -90,14 +90,21 @@ class ACR(object):
     __call__ = forward
 
     @torch.no_grad()
-    def forward_batch(self, rgb_u8_frames, paths, offsets=None):
+    def forward_batch(self, rgb_u8_frames, paths, offsets=None, point_heads=True):
         """Batched throughput path: uint8 [B,512,512,3] RGB (already pre-processed) -> per-image results.
-        One fused call (backbone, heads, decode, MANO, projection) + one D2H of the packed results."""
+        One fused call (backbone, heads, decode, MANO, projection) + one D2H of the packed results.
+        The head maps are not part of these results, so by default the params/cam/prior towers run only at the
+        decoded centers (Engine.set_point_heads; same results within fp32 round-off) - point_heads=False runs the
+        dense heads as `forward` does."""
         eng = self.model.engine(rgb_u8_frames.shape[0])
         B = rgb_u8_frames.shape[0]
         if offsets is None:
             offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(B, 1)
-        out = eng.forward(rgb_u8_frames, offsets=offsets, project=True)
+        eng.set_point_heads(point_heads)
+        try:
+            out = eng.forward(rgb_u8_frames, offsets=offsets, project=True)
+        finally:
+            eng.set_point_heads(False)
         slots = out['slots'].cpu().numpy()
         host = {k: out[k].cpu().numpy() for k in ('verts', 'joints', 'pj2d', 'pj2d_org')}
         from .. import _lib as S

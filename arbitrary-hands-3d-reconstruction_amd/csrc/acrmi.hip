@@ -4,12 +4,29 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 using namespace acrmi;
 
+// ---- op dependencies and stream lanes ----------------------------------------------------------------
+constexpr int MAX_LANES = 8;
+// ACRMI_OPT_LANES = 0: measured on MI355X (tools/lanes_check.py) - batch 1: 6.97 ms on one stream, 4.63 on four;
+// batch 64: 46.9 ms on one, 45.6 on two (the second lane fills the tails and pipeline fills of the first), 45.8 on three
+constexpr int AUTO_LANES_SMALL = 4, AUTO_LANES_LARGE = 2, AUTO_SMALL_BATCH = 16;
+struct Schedule {
+  std::vector<int> order;               // active op indices, program order (a topological order)
+  std::vector<std::vector<int>> deps;   // per op: earlier ops it must wait for (RAW / WAR / WAW on buffer ids)
+  std::vector<char> leaf;               // per op: no later op depends on it
+  // multi-stream form (ACRMI_OPT_LANES): lane per op, events of other lanes' ops to wait for, event to record
+  int n_lanes = 0;
+  std::vector<int> lane;
+  std::vector<std::vector<int>> wait;
+  std::vector<char> signal;
+};
 struct acrmi_ctx {
   int device = 0;
   std::string err;
@@ -25,6 +42,13 @@ struct acrmi_ctx {
   size_t att_ws_floats = 0;
   int* picks = nullptr;         // point heads: decoded centers per frame [max_batch,4]
   bool point_heads = false;     // ACRMI_OPT_POINT_HEADS
+  Schedule sched[2][2];         // [point][0: small batches / 1: large batches]
+  // ACRMI_OPT_LANES: independent chains of the program on parallel HIP streams (lane 0 = the caller's stream)
+  int want_lanes = 0;           // 0 = by batch size (AUTO_LANES_*)
+  hipStream_t lanes[MAX_LANES] = {};
+  hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {};
+  std::vector<hipEvent_t> op_ev;
+  unsigned long long tick = 0;
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
   std::vector<float*> mano_allocs;
@@ -69,6 +93,9 @@ int acrmi_create(acrmi_ctx** out, int device) {
 }
 
 static void free_program(acrmi_ctx* c) {
+  for (hipEvent_t e : c->op_ev)
+    if (e) (void)hipEventDestroy(e);
+  c->op_ev.clear();
   for (float* p : c->buf_ptr)
     if (p) (void)hipFree(p);
   c->buf_ptr.clear();
@@ -85,6 +112,11 @@ void acrmi_destroy(acrmi_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   free_program(c);
+  for (int l = 0; l < MAX_LANES; ++l) {
+    if (c->lanes[l]) (void)hipStreamDestroy(c->lanes[l]);
+    if (c->join_ev[l]) (void)hipEventDestroy(c->join_ev[l]);
+  }
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   if (c->weights) (void)hipFree(c->weights);
   for (float* p : c->mano_allocs) (void)hipFree(p);
   delete c;
@@ -203,6 +235,96 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
   }
 }
 
+// ops of the other head variant are skipped
+static inline bool op_active(const acrmi_op& op, bool point) {
+  return op.kind != ACRMI_OP_COORDFILL && op.mode != (point ? ACRMI_MODE_DENSE : ACRMI_MODE_POINT);
+}
+
+// Buffers an op reads / writes (whole buffers: channel slices of one buffer are ordered conservatively).
+// Pseudo-buffers n_bufs / n_bufs+1 stand for the attention-pool and center-pick workspaces.
+static void op_rw(const acrmi_ctx* c, const acrmi_op& op, std::vector<int>& R, std::vector<int>& W) {
+  R.clear(); W.clear();
+  const int n_bufs = (int)c->bufs.size();
+  auto r = [&](int id) { if (id >= 0) R.push_back(id); };
+  auto w = [&](int id) { if (id >= 0) W.push_back(id); };
+  switch (op.kind) {
+    case ACRMI_OP_U8NORM: w(op.out_buf); break;
+    case ACRMI_OP_CONV: r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf); w(op.out_buf); break;
+    case ACRMI_OP_FUSESUM: for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]); w(op.out_buf); break;
+    case ACRMI_OP_BILINEAR2X: r(op.in_buf); w(op.out_buf); break;
+    case ACRMI_OP_POW11: r(op.out_buf); w(op.out_buf); break;
+    case ACRMI_OP_ATTPOOL: r(op.in_buf); r(op.res_buf); w(op.out_buf); w(n_bufs); break;
+    case ACRMI_OP_PAREBIAS: r(op.in_buf); w(op.out_buf); break;
+    case ACRMI_OP_POINTHEADS:
+      r(op.in_buf); r(op.aux_buf); r(c->heads.center_buf[0]); r(c->heads.center_buf[1]);
+      w(op.res_buf); w(op.out_buf); w(c->heads.prior_buf[op.flags & 1]); w(n_bufs + 1);
+      break;
+    default: break;
+  }
+}
+
+// Dependencies between ops: RAW/WAR/WAW hazards on buffer ids (ids are reused for disjoint lifetimes, which
+// the WAR edges respect).  The program order is a topological order.
+static void build_schedule(acrmi_ctx* c, bool point, bool large) {
+  Schedule& S = c->sched[point ? 1 : 0][large ? 1 : 0];
+  const int n = (int)c->ops.size(), nb = (int)c->bufs.size() + 2;
+  S = Schedule();
+  S.deps.assign(n, std::vector<int>());
+  S.leaf.assign(n, 1);
+  std::vector<int> last_writer(nb, -1), R, W;
+  std::vector<std::vector<int>> readers(nb);
+  for (int j = 0; j < n; ++j) {
+    if (!op_active(c->ops[j], point)) continue;
+    S.order.push_back(j);
+    op_rw(c, c->ops[j], R, W);
+    std::vector<int>& deps = S.deps[j];
+    auto dep = [&](int i) { if (i >= 0 && i != j && std::find(deps.begin(), deps.end(), i) == deps.end()) deps.push_back(i); };
+    for (int b : R) dep(last_writer[b]);
+    for (int b : W) { dep(last_writer[b]); for (int i : readers[b]) dep(i); }
+    for (int b : R) readers[b].push_back(j);
+    for (int b : W) { last_writer[b] = j; readers[b].clear(); }
+    for (int d : deps) S.leaf[d] = 0;
+  }
+  // lanes: an op continues the lane of a producer that is still that lane's tail (the producer of in_buf first),
+  // otherwise it opens a lane, or takes the one whose tail is oldest
+  const int want = c->want_lanes > 0 ? c->want_lanes : (large ? AUTO_LANES_LARGE : AUTO_LANES_SMALL);
+  const int max_lanes = std::max(1, std::min(want, MAX_LANES));
+  S.lane.assign(n, 0);
+  S.wait.assign(n, std::vector<int>());
+  S.signal.assign(n, 0);
+  std::vector<int> lane_tail(max_lanes, -1);
+  for (int j : S.order) {
+    int lane = -1;
+    for (int d : S.deps[j])
+      if (lane_tail[S.lane[d]] == d) { lane = S.lane[d]; break; }
+    if (lane < 0) {
+      if (S.n_lanes < max_lanes) lane = S.n_lanes++;
+      else lane = (int)(std::min_element(lane_tail.begin(), lane_tail.end()) - lane_tail.begin());
+    }
+    S.lane[j] = lane;
+    std::vector<int> latest(max_lanes, -1);      // waiting for a lane's latest op covers its earlier ones
+    for (int d : S.deps[j])
+      if (S.lane[d] != lane && d > latest[S.lane[d]]) latest[S.lane[d]] = d;
+    for (int l = 0; l < max_lanes; ++l)
+      if (latest[l] >= 0) { S.wait[j].push_back(latest[l]); S.signal[latest[l]] = 1; }
+    lane_tail[lane] = j;
+  }
+  if (getenv("ACRMI_DEBUG_SCHED")) {
+    // depth of the DAG = kernels on the critical path (a single stream runs all of S.order in sequence)
+    std::vector<int> depth(n, 0);
+    int edges = 0, maxd = 0;
+    for (int j : S.order) {
+      for (int d : S.deps[j]) depth[j] = std::max(depth[j], depth[d] + 1);
+      edges += (int)S.deps[j].size();
+      maxd = std::max(maxd, depth[j] + 1);
+    }
+    int waits = 0;
+    for (int j : S.order) waits += (int)S.wait[j].size();
+    fprintf(stderr, "[acrmi] schedule(%s, %s batches): %zu ops, %d edges, critical path %d ops; %d lanes, %d cross-lane waits\n",
+            point ? "point" : "dense", large ? "large" : "small", S.order.size(), edges, maxd, S.n_lanes, waits);
+  }
+}
+
 int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, const acrmi_op* ops, int n_ops,
                       const acrmi_head_layout* heads, int max_batch) {
   if (!c || !bufs || !ops || !heads || n_bufs <= 0 || n_ops <= 0 || max_batch <= 0)
@@ -242,6 +364,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
   HIPCHK(c, hipMalloc(&c->picks, (size_t)max_batch * 4 * sizeof(int)));
+  for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
+  c->op_ev.assign(n_ops, nullptr);
   c->have_program = true;
   // init-time ops (constants that live in persistent buffers)
   for (const acrmi_op& op : c->ops)
@@ -284,9 +408,34 @@ int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float
   return ACRMI_OK;
 }
 
-// ops of the other head variant are skipped
-static inline bool op_active(const acrmi_op& op, bool point) {
-  return op.kind != ACRMI_OP_COORDFILL && op.mode != (point ? ACRMI_MODE_DENSE : ACRMI_MODE_POINT);
+// The program with its independent chains on parallel streams: lane 0 is the caller's stream, the other lanes fork
+// from it (so they start after everything queued before this call) and join it at the end.
+static int run_program_lanes(acrmi_ctx* c, const uint8_t* img, int B, hipStream_t user, bool point) {
+  const Schedule& S = c->sched[point ? 1 : 0][B > AUTO_SMALL_BATCH ? 1 : 0];
+  for (int l = 1; l < S.n_lanes; ++l) {
+    if (!c->lanes[l]) HIPCHK(c, hipStreamCreateWithFlags(&c->lanes[l], hipStreamNonBlocking));
+    if (!c->join_ev[l]) HIPCHK(c, hipEventCreateWithFlags(&c->join_ev[l], hipEventDisableTiming));
+  }
+  if (!c->fork_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+  auto st = [&](int l) { return l == 0 ? user : c->lanes[l]; };
+  HIPCHK(c, hipEventRecord(c->fork_ev, user));
+  for (int l = 1; l < S.n_lanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], c->fork_ev, 0));
+  int r = ACRMI_OK;
+  for (int j : S.order) {
+    hipStream_t s = st(S.lane[j]);
+    for (int d : S.wait[j]) HIPCHK(c, hipStreamWaitEvent(s, c->op_ev[d], 0));
+    r = run_op(c, c->ops[j], img, B, s);
+    if (r) break;
+    if (S.signal[j]) {
+      if (!c->op_ev[j]) HIPCHK(c, hipEventCreateWithFlags(&c->op_ev[j], hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->op_ev[j], s));
+    }
+  }
+  for (int l = 1; l < S.n_lanes; ++l) {       // join also on the error path: nothing may outlive the call unordered
+    HIPCHK(c, hipEventRecord(c->join_ev[l], c->lanes[l]));
+    HIPCHK(c, hipStreamWaitEvent(user, c->join_ev[l], 0));
+  }
+  return r;
 }
 
 static int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point) {
@@ -294,6 +443,8 @@ static int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bo
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_heads: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
   static const bool dbg_sync = getenv("ACRMI_DEBUG_SYNC") != nullptr;   // attribute a fault/hang to an op
+  if (c->sched[point ? 1 : 0][B > AUTO_SMALL_BATCH ? 1 : 0].n_lanes > 1 && !dbg_sync)
+    return run_program_lanes(c, img, B, (hipStream_t)stream, point);
   int i = 0;
   for (const acrmi_op& op : c->ops) {
     ++i;
@@ -334,6 +485,13 @@ int acrmi_set_option(acrmi_ctx* c, int option, int value) {
       if (!any) return fail(c, ACRMI_EINVAL, "acrmi_set_option: the program has no point-heads ops");
     }
     c->point_heads = value != 0;
+    return ACRMI_OK;
+  }
+  if (option == ACRMI_OPT_LANES) {
+    if (value < 0 || value > MAX_LANES) return fail(c, ACRMI_EINVAL, "acrmi_set_option: lanes %d outside 0..%d", value, MAX_LANES);
+    c->want_lanes = value;
+    if (c->have_program)
+      for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
     return ACRMI_OK;
   }
   return fail(c, ACRMI_EINVAL, "acrmi_set_option: unknown option %d", option);
@@ -422,13 +580,10 @@ int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* b
   return ACRMI_OK;
 }
 
-int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets, float* slots, float* verts,
-                  float* joints, float* verts_camed, float* pj2d, float* pj2d_org, void* stream) {
-  if (!c || !slots || !verts || !joints) return fail(c, ACRMI_EINVAL, "acrmi_forward: bad arguments");
-  if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_forward: MANO tables not loaded");
-  int r = run_program(c, img, B, stream, c->point_heads);
-  if (r) return r;
-  r = acrmi_decode(c, B, slots, stream);
+// decode + MANO of acrmi_forward on one stream
+static int forward_tail(acrmi_ctx* c, int B, const float* offsets, float* slots, float* verts, float* joints,
+                        float* verts_camed, float* pj2d, float* pj2d_org, hipStream_t stream) {
+  int r = acrmi_decode(c, B, slots, stream);
   if (r) return r;
   ManoArgs m{};
   m.t[0] = c->mano[0]; m.t[1] = c->mano[1];
@@ -440,8 +595,17 @@ int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets,
   m.cam = proj ? slots + ACRMI_SLOT_CAM : nullptr; m.cam_stride = ACRMI_SLOT;
   m.offsets = offsets; m.off_div = 2;
   m.verts_camed = verts_camed; m.pj2d = pj2d; m.pj2d_org = pj2d_org;
-  HIPCHK(c, launch_mano(m, (hipStream_t)stream));
+  HIPCHK(c, launch_mano(m, stream));
   return ACRMI_OK;
+}
+
+int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets, float* slots, float* verts,
+                  float* joints, float* verts_camed, float* pj2d, float* pj2d_org, void* stream) {
+  if (!c || !slots || !verts || !joints) return fail(c, ACRMI_EINVAL, "acrmi_forward: bad arguments");
+  if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_forward: MANO tables not loaded");
+  int r = run_program(c, img, B, stream, c->point_heads);
+  if (r) return r;
+  return forward_tail(c, B, offsets, slots, verts, joints, verts_camed, pj2d, pj2d_org, (hipStream_t)stream);
 }
 
 // ---- stand-alone operators -------------------------------------------------------------------------

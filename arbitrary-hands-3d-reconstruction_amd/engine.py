@@ -28,6 +28,7 @@ class Engine(object):
         self.program = None
         self.have_mano = False
         self.point_heads = False
+        self.lanes = 0
 
     def close(self):
         if self.ctx:
@@ -65,6 +66,12 @@ class Engine(object):
         round-off; `head_maps` params/prior maps are then only valid after `backbone_heads` (always dense)."""
         _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_POINT_HEADS, int(bool(on))), self.ctx)
         self.point_heads = bool(on)
+
+    def set_lanes(self, n):
+        """ACRMI_OPT_LANES: independent chains of the program on n parallel HIP streams (1 = single stream,
+        0 = by batch size: the library default)."""
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_LANES, int(n)), self.ctx)
+        self.lanes = int(n)
 
     def run_point_heads(self, B):
         """Re-evaluates the point heads on the resident buffers for the current center maps (acrmi_point_heads)."""

@@ -17,7 +17,11 @@ import os
 import sys
 import time
 
-import torch
+# parallel lanes + RCCL need more than ROCm's default 4 hardware queues per process (see the package __init__);
+# must be set before the HIP runtime initialises
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -84,6 +88,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='frames per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-point-heads', action='store_true', help='skip the separately reported point-heads variant')
+    ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default)')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
     args = ap.parse_args()
 
@@ -116,6 +121,7 @@ def main():
     eng.load_state_dict(sd, max_batch=B)
     eng.load_mano(tables)
     frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False)).cuda()   # resident in HBM
+    eng.set_lanes(args.lanes)
 
     flat, views = parallel.alloc_result(B, eng.device)
 

@@ -89,8 +89,12 @@ def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
             assert h[k].dtype == np.float16, k
         assert np.abs(h['verts'].astype(np.float32) - g['f0_verts'][i]).max() < 2e-3       # fp16 packaging
         assert np.abs(h['poses'].astype(np.float32) - g['f0_poses'][i]).max() < 5e-3
-    batch = acr.forward_batch(torch.from_numpy(frames2), ['a', 'b'])
+    batch = acr.forward_batch(torch.from_numpy(frames2), ['a', 'b'])                    # point heads (default)
     assert np.abs(batch['b'][1]['verts'].astype(np.float32) - g['f1_verts'][1]).max() < 2e-3
+    dense = acr.forward_batch(torch.from_numpy(frames2), ['a', 'b'], point_heads=False)
+    for path in ('a', 'b'):
+        for hp, hd in zip(batch[path], dense[path]):
+            assert np.abs(hp['verts'].astype(np.float32) - hd['verts'].astype(np.float32)).max() < 1e-3   # 1 fp16 ulp
     # nothing detected -> {path: {}}
     sd = pkg('synth').make_state_dict(seed=0, center_bias=(-50.0, -50.0))
     acr2 = pkg('acr.main').ACR(state_dict=sd, mano_tables=mano_tables)

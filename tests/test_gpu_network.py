@@ -176,6 +176,40 @@ def test_point_heads_at_map_borders_and_without_detections(engine, synth_sd):
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=5e-5, atol=5e-5)
 
 
+def test_parallel_lanes_are_bit_identical(engine, frames2):
+    """ACRMI_OPT_LANES: the program's independent chains (HRNet branches, head towers, segm / part heads - found from
+    the ops' buffer reads and writes) on 2..8 HIP streams forked from / joined to the caller's stream give bit-identical
+    maps, slots and meshes to the single-stream run, in the dense and the point-heads variant, call after call."""
+    x = torch.from_numpy(frames2).cuda()
+    other = torch.from_numpy(pkg('synth').make_frames(2, seed=5, structured=True)).cuda()
+    offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(2, 1).cuda()
+    engine.set_lanes(1)
+    B = engine.backbone_heads(x)
+    maps1 = {k: v.clone() for k, v in engine.head_maps(B).items()}
+    want = {}
+    for point in (False, True):
+        engine.set_point_heads(point)
+        want[point] = [{k: v.clone() for k, v in engine.forward(f, offsets=offsets, project=True).items()} for f in (x, other)]
+    try:
+        for lanes in (2, 4, 8):
+            engine.set_lanes(lanes)
+            B = engine.backbone_heads(x)
+            for k, v in engine.head_maps(B).items():
+                assert torch.equal(v, maps1[k]), (lanes, k)
+            for point in (False, True):
+                engine.set_point_heads(point)
+                for rep in range(3):                     # back-to-back calls: the next call's lanes may not overtake
+                    for f, w in zip((x, other), want[point]):
+                        out = engine.forward(f, offsets=offsets, project=True)
+                        for k in w:
+                            assert torch.equal(out[k], w[k]), (lanes, point, rep, k)
+        with pytest.raises(ValueError):
+            engine.set_lanes(9)
+    finally:
+        engine.set_point_heads(False)
+        engine.set_lanes(0)
+
+
 def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
     """BASELINE.json's bench configuration (batch 64, 512x512): size-independent properties of the whole path.
     Frames are independent, so (i) the two golden frames planted anywhere in the batch of 64 reproduce the reference's
@@ -205,7 +239,12 @@ def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
             assert torch.equal(out['slots'][p], small['slots'][b])
             assert np.abs(out['verts'][p].cpu().numpy() - g['f%d_verts' % b]).max() < 1e-4
             assert np.abs(out['joints'][p].cpu().numpy() - g['f%d_j3d' % b]).max() < 1e-4
-    eng.set_point_heads(True)                                # (iv) the point-heads variant agrees on all 128 hands
+    eng.set_lanes(1)                                         # (iv) single stream vs the default lanes: bit-identical
+    lan = eng.forward(x)
+    eng.set_lanes(0)
+    for k in ('slots', 'verts', 'joints'):
+        assert torch.equal(lan[k], out[k]), k
+    eng.set_point_heads(True)                                # (v) the point-heads variant agrees on all 128 hands
     pt = {k: v.clone() for k, v in eng.forward(x).items()}
     eng.set_point_heads(False)
     _assert_point_matches_dense(pt, out)
