@@ -192,6 +192,17 @@ class Program(object):
         cout, cin_w = wb_list[0][0].shape[:2]
         cin = cin_w if cin is None else cin
         ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w_ + 2 * (k // 2) - k) // stride + 1
+        flop_cout = cout
+        if out is None and out_c is None and len(wb_list) == 1 and k == 3 and stride == 1 and cout < 32 and res is None:
+            # a Cout < 32 tile takes the Winograd kernel's element-wise epilogue (16 scalar stores per lane); padded to
+            # a full 32-cout tile with zero filters it takes the vector one (the extra channels are written as
+            # relu(0) = 0 into a 32-wide buffer and never read: the consumer's Cin stays cout)
+            w0, b0 = wb_list[0]
+            wp = np.zeros((32,) + w0.shape[1:], w0.dtype)
+            wp[:cout] = w0
+            bp = np.zeros(32, b0.dtype)
+            bp[:cout] = b0
+            wb_list, cout = [(wp, bp)], 32
         if out is None:
             out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
         algo = conv_algo(k, stride, cin, cout)
@@ -199,7 +210,7 @@ class Program(object):
         packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
         w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
-        flops = 2.0 * ho * wo * cout * cin_w * k * k * len(wb_list)     # algorithmic (direct-conv) FLOPs
+        flops = 2.0 * ho * wo * flop_cout * cin_w * k * k * len(wb_list)     # algorithmic (direct-conv) FLOPs
         self._op(name, flops, kind=_lib.OP_CONV, in_buf=src, out_buf=out, res_buf=-1 if res is None else res,
                  in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
                  relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=algo,
