@@ -621,6 +621,10 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: input channel stride/offset must be multiples of 4");
+  if (in_coff < 0 || out_coff < 0 || res_coff < 0 || in_coff + groups * cin > in_cs || out_coff + groups * cout > out_cs ||
+      (res && res_coff + groups * cout > res_cs) || bias_frame_stride < 0 ||
+      (bias_frame_stride > 0 && bias_frame_stride < groups * cout))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: channel slice outside its tensor's channel stride");
   ConvArgs a{};
   a.in = in; a.w = w_packed; a.bias = bias; a.res = res; a.out = out;
   a.B = B; a.H = H; a.W = W;

@@ -182,6 +182,60 @@ def test_conv_stride2_groups_and_slices(ops):
     assert (_nchw(out, 96).double() - ref).abs().max().item() < 2e-5
 
 
+def _random_conv_case(rs):
+    k, stride = [(3, 1), (3, 1), (3, 2), (1, 1)][rs.randint(4)]
+    groups = [1, 1, 1, 2, 4][rs.randint(5)]
+    cin_g = int(rs.choice([4, 8, 12, 16, 20, 32, 36, 48, 64, 72])) if groups > 1 else int(rs.randint(1, 97))
+    cout_g = int(rs.randint(1, 100))
+    algo = 'direct' if (k, stride) != (3, 1) else ['direct', 'winograd', 'winograd2d', 'winograd2d'][rs.randint(4)]
+    return dict(B=int(rs.randint(1, 4)), H=int(rs.randint(1, 41)), W=int(rs.randint(1, 41)), k=k, stride=stride,
+                groups=groups, cin_g=cin_g, cout_g=cout_g, algo=algo, relu=bool(rs.randint(2)), res=bool(rs.randint(2)),
+                frame_bias=bool(rs.randint(3) == 0) and groups == 1, in_coff=4 * int(rs.randint(0, 3)),
+                out_coff=int(rs.randint(0, 7)), in_tail=4 * int(rs.randint(0, 3)), out_tail=int(rs.randint(0, 6)))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_conv2d_random_sweep(ops, seed):
+    """Seeded sweep over what the hand-picked cases leave out: random sizes down to 1x1 frames, ragged channel counts,
+    groups, channel slices on both sides, per-frame bias rows, residuals, all three algorithms (12 configurations per
+    seed).  Reference: fp64 torch convolution."""
+    rs = np.random.RandomState(1000 + seed)
+    for it in range(12):
+        c = _random_conv_case(rs)
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        cin, cout = c['cin_g'] * c['groups'], c['cout_g'] * c['groups']
+        in_cs = (c['in_coff'] + cin + c['in_tail'] + 3) // 4 * 4
+        out_cs = c['out_coff'] + cout + c['out_tail']
+        xw = torch.randn(c['B'], in_cs, c['H'], c['W'], generator=g)
+        w = torch.randn(cout, c['cin_g'], c['k'], c['k'], generator=g) / np.sqrt(c['cin_g'] * c['k'] ** 2)
+        b = torch.randn(cout, generator=g) * 0.1
+        x = xw[:, c['in_coff']:c['in_coff'] + cin]
+        ref = F.conv2d(x.double(), w.double(), None, c['stride'], c['k'] // 2, 1, c['groups'])
+        fb = None
+        if c['frame_bias']:
+            fb = torch.randn(c['B'], cout + int(rs.randint(0, 5)), generator=g)
+            ref = ref + fb[:, :cout, None, None].double()
+        else:
+            ref = ref + b.double()[None, :, None, None]
+        res = None
+        if c['res']:
+            res = torch.randn(ref.shape, generator=g)
+            ref = ref + res.double()
+        if c['relu']:
+            ref = F.relu(ref)
+        Ho, Wo = ref.shape[2:]
+        dst = torch.full((c['B'], Ho, Wo, out_cs), 7.0, device='cuda')
+        ops.conv2d(ops.to_nhwc(xw), w, None if c['frame_bias'] else b, stride=c['stride'], relu=c['relu'],
+                   groups=c['groups'], cin=c['cin_g'], in_coff=c['in_coff'], out=dst, out_coff=c['out_coff'],
+                   frame_bias=None if fb is None else fb.cuda(), residual=None if res is None else ops.to_nhwc(res),
+                   algo=c['algo'])
+        torch.cuda.synchronize()
+        got = dst[..., c['out_coff']:c['out_coff'] + cout].permute(0, 3, 1, 2).cpu().double()
+        err = (got - ref).abs().max().item()
+        assert err < 6e-5, (seed, it, c, err)
+        assert (dst[..., :c['out_coff']] == 7).all() and (dst[..., c['out_coff'] + cout:] == 7).all(), (seed, it, c)
+
+
 def test_conv2d_rejects_unsupported(ops):
     x = torch.zeros(1, 8, 8, 8, device='cuda')
     with pytest.raises(ValueError):
