@@ -401,19 +401,50 @@ def lower(sd, check=True, point_heads=True):
         P.release(t1, t0)
         t0 = t2
     heads = _lib.HeadLayout()
-    p109 = {}
-    for si, side in enumerate('lr'):
-        p109[side] = P.buf(64, 64, 109)
-        center = P.buf(64, 64, 1, persistent=True)
-        prior = P.buf(64, 64, 106, persistent=True)
-        for k, (dst, coff) in ((1, (p109[side], 3)), (2, (center, 0)), (3, (p109[side], 0)), (4, (prior, 0))):
-            ti = towers.index((side, k))
-            name = '%s_final_layers.%d.2' % (side, k)
-            n0 = len(P.ops)
-            P.conv(name, t0, [P.folded(name)], 1, 1, False, out=dst, in_coff=64 * ti, out_coff=coff, cin=64)
-            if k != 2:
-                P.set_mode(_lib.MODE_DENSE, n0)
-        P._op('%s.cam_pow' % side, 0.0, kind=_lib.OP_POW11, out_buf=p109[side], out_coff=0, mode=_lib.MODE_DENSE)
+
+    def padded(w, b, n):
+        """[Cout,...] filters zero-padded to n output channels: whole 32-cout tiles take the kernels' vector epilogue
+        (the element-wise one costs 2x on these small layers); the extra channels land in the buffer's pad."""
+        wp = np.zeros((n,) + w.shape[1:])
+        wp[:w.shape[0]] = w
+        bp = np.zeros(n)
+        bp[:b.shape[0]] = b
+        return wp, bp
+
+    # Exits (acr/model.py:305-311) and the mix conv (:160-164).  Between the params exit and the mix conv there is
+    # no non-linearity, so the dense program applies their product to the tower features directly:
+    #   final = (W_mix[:, params] W_exit_p) t_p + W_mix[:, params] b_exit_p          "params_mix", at the exit stage
+    #         + W_mix[:, cam] cam' + per-frame pare bias                             "cam_mix", once the bias exists
+    # with cam' = the 3-channel cam exit after 1.1**x on channel 0 (:95-96).  The 106-channel intermediate map is never
+    # written.  (The point-heads variant evaluates exit and mix per pixel and keeps its own weights.)
+    p109, final, camb = {}, {}, {}
+    mix_w = {}
+    for si, (side, mix) in enumerate((('l', 4), ('r', 5))):
+        wm = _np(sd['contact_layers.%d.weight' % mix]).astype(np.float64).reshape(109, 218)
+        wa = wm[:, :109].copy()
+        wa[:, :3] += wm[:, 109:112]                 # cam3 appears twice in the concat (acr/model.py:160-163)
+        mix_w[side] = (wa, wm[:, 112:])
+        p109[side] = P.buf(64, 64, 109)              # point heads: raw exits of the sampled pixel
+        final[side] = P.buf(64, 64, 128, persistent=True)
+        camb[side] = P.buf(64, 64, 32)
+        center = P.buf(64, 64, 32, persistent=True)
+        prior = P.buf(64, 64, 128, persistent=True)
+        name = '%s_final_layers.%%d.2' % side
+        tin = lambda k: 64 * towers.index((side, k))
+        P.conv(name % 2, t0, [padded(*P.folded(name % 2), 32)], 1, 1, False, out=center, in_coff=tin(2), cin=64)
+        P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 64 * 1
+        n0 = len(P.ops)
+        we, be = P.folded(name % 1)
+        wc = wa[:, 3:] @ we[:, :, 0, 0]              # [109,64]
+        P.conv(side + '.params_mix', t0, [padded(wc[:, :, None, None], wa[:, 3:] @ be, 128)], 1, 1, False,
+               out=final[side], in_coff=tin(1), cin=64)
+        P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 64 * 106
+        P.conv(name % 3, t0, [padded(*P.folded(name % 3), 32)], 1, 1, False, out=camb[side], in_coff=tin(3), cin=64)
+        P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 64 * 3
+        P._op('%s.cam_pow' % side, 0.0, kind=_lib.OP_POW11, out_buf=camb[side], out_coff=0)
+        P.conv(name % 4, t0, [padded(*P.folded(name % 4), 128)], 1, 1, False, out=prior, in_coff=tin(4), cin=64)
+        P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 64 * 106
+        P.set_mode(_lib.MODE_DENSE, n0)
         heads.center_buf[si], heads.prior_buf[si] = center, prior
     P.release(t0)
     # ---- part branch (acr/model.py:116-166) ---------------------------------------------------------
@@ -424,30 +455,26 @@ def lower(sd, check=True, point_heads=True):
     P._op('attpool', 2.0 * 32 * 16384 * 320, kind=_lib.OP_ATTPOOL, in_buf=segm, res_buf=feat, out_buf=pooled, cin=320)
     P.release(feat)
     for si, (side, lc, mix, part0) in enumerate((('l', 2, 4, 16), ('r', 3, 5, 0))):
-        wm = sd['contact_layers.%d.weight' % mix]
-        wm = _np(wm).astype(np.float64).reshape(109, 218)
-        wa = wm[:, :109].copy()
-        wa[:, :3] += wm[:, 109:112]                 # cam3 appears twice in the concat (acr/model.py:160-163)
-        wp = wm[:, 112:]
-        bias_buf = P.buf(1, 1, 112, persistent=True)     # one per side: acrmi_point_heads re-reads both
+        wa, wp = mix_w[side]
+        bias_buf = P.buf(1, 1, 128, persistent=True)     # one per side: acrmi_point_heads re-reads both
         P._op('%s.parebias' % side, 0.0, kind=_lib.OP_PAREBIAS, in_buf=pooled, out_buf=bias_buf, cin=320, flags=part0,
               w_off=P.blob.add(_np(sd['contact_layers.%d.weight' % lc]).reshape(6, 256, 16)),
               w_off2=P.blob.add(_np(sd['cam_shape_layers.%d.weight' % lc])),
               b_off2=P.blob.add(_np(sd['cam_shape_layers.%d.bias' % lc])),
               w_off3=P.blob.add(wp), b_off=P.blob.add(_np(sd['contact_layers.%d.bias' % mix])))
-        final = P.buf(64, 64, 109, persistent=True)
         n0 = len(P.ops)
-        P.conv('contact_layers.%d' % mix, p109[side], [(wa.reshape(109, 109, 1, 1), np.zeros(109))], 1, 1, False,
-               out=final, cin=109, bias_buf=bias_buf)
+        P.conv('contact_layers.%d' % mix, camb[side], [padded(wa[:, :3, None, None], np.zeros(109), 128)], 1, 1, False,
+               out=final[side], cin=3, bias_buf=bias_buf, res=final[side])
         P.op_info[-1]['flops'] = 2.0 * 64 * 64 * 109 * 218
         P.set_mode(_lib.MODE_DENSE, n0)
+        P.release(camb[side])
         if point_heads:
             mixw = np.zeros((109, 112))
             mixw[:, :109] = wa.T
-            P._op('%s.point_heads' % side, 0.0, kind=_lib.OP_POINTHEADS, in_buf=x34, res_buf=p109[side], out_buf=final,
+            P._op('%s.point_heads' % side, 0.0, kind=_lib.OP_POINTHEADS, in_buf=x34, res_buf=p109[side], out_buf=final[side],
                   aux_buf=bias_buf, flags=si, mode=_lib.MODE_POINT,
                   w_off=P.blob.add(np.concatenate([point_tower(P, side, k) for k in (1, 3, 4)])),
                   w_off2=P.blob.add(mixw))
-        heads.params_buf[si] = final
+        heads.params_buf[si] = final[side]
     heads.segm_buf, heads.backbone_buf = segm, x34
     return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info}
