@@ -613,7 +613,9 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;
     // two n-tiles per wave need two Cin chunks per item (single-buffered exchange area); Cin <= 32 runs one
     // n-tile per wave and one 32-cout block per work item instead
-    const bool nt1 = n32 || a.cin8 * 8 <= 32;
+    // Cout = 33 with more than one Cin chunk: one regular tile + the 33rd channel on 4x4x1 MFMAs (conv_wino2.inc ODD)
+    const bool odd33 = a.Cout == 33 && a.groups == 1 && a.cin8 * 8 > 32 && g_force_cfg != 804;
+    const bool nt1 = n32 || a.cin8 * 8 <= 32 || odd33;
     if (g_force_cfg == 801) return nt1 ? launch_wino2<1, 32, 4>(a, s) : launch_wino2<2, 32, 4>(a, s);
     return nt1 ? launch_wino2<1, 32, 2>(a, s) : launch_wino2<2, 32, 2>(a, s);
   }

@@ -63,6 +63,11 @@ def pack_conv(w, b):
     wp = np.zeros((nt * 32, c8 * 8, kh, kw), np.float32)
     wp[:cout, :cin] = w
     wp = wp.reshape(nt, 32, c8, 2, 4, kh, kw)           # [nt, j, s, h, e, ky, kx]
+    if cout == 33 and (kh, kw) == (4, 4):
+        # F(2x2,3x3) taps of a 33-cout conv: conv_wino2_kernel's ODD path feeds the 33rd channel to 4x4x1 MFMAs, which
+        # take a block's weight from the row of its first lane - cout 32 replicated into every 4th row of tile 1.  The
+        # extra rows are couts 36, 40, ... of the regular layout: never stored, so every other path stays correct.
+        wp[1, 4::4] = wp[1, 0:1]
     wp = wp.transpose(5, 6, 2, 0, 3, 1, 4)               # [ky, kx, s, nt, h, j, e]
     bp = np.zeros(nt * 32, np.float32)
     bp[:cout] = b

@@ -106,6 +106,9 @@ WINO2D_CASES = WINO_CASES + [
     (3, 40, 40, 24, 32, 3, 1, 1, True, True),        # 2 chunks (32 + 8), several items per workgroup? no: 36 items
     (1, 96, 64, 8, 16, 3, 1, 1, False, False),       # one tile, three full chunks
     (2, 8, 24, 16, 32, 3, 1, 1, True, True),         # single one-step chunk per item, double-buffered exchange
+    (2, 64, 33, 32, 32, 3, 1, 1, True, True),        # 33rd channel on 4x4x1 MFMAs (segm_net conv 0), with residual
+    (1, 40, 33, 19, 23, 3, 1, 1, False, True),       # ... ragged tiles and a short last chunk
+    (3, 96, 33, 8, 16, 3, 1, 1, True, False),        # ... three chunks, one tile per frame
 ]
 
 
