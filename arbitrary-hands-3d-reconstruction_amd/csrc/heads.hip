@@ -124,6 +124,9 @@ hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int
   if (C == 320)
     hipLaunchKernelGGL(att_pool_kernel<10>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
                        stats_ws, part_ws);
+  else if (C == 256)
+    hipLaunchKernelGGL(att_pool_kernel<8>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
+                       stats_ws, part_ws);
   else if (C == 64)
     hipLaunchKernelGGL(att_pool_kernel<2>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
                        stats_ws, part_ws);
@@ -139,12 +142,16 @@ hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int
 // ------------------------------------------------------------------------------------------------
 // pare bias (acr/model.py:141-164): per frame and hand
 //   offsets[j*6+o] = sum_c LC[o][c][j] * pooled[part0+j][c]            (LocallyConnected2d, :559-569)
-//   shape[k]       = lin_b[k] + sum_{c,j} lin_w[k][c*16+j] * pooled[part0+j][256+c]
+//   shape[k]       = lin_b[k] + sum_{c,j} lin_w[k][c*16+j] * pooled[part0+j][shape_c0+c],  c < shape_nc
+//   (C = 320: the reference's layout, 64 shape channels behind the 256 contact ones.  C = 256: the program's - the
+//   1x1 shape conv (acr/model.py:132) is linear and the softmax weights of a part sum to 1, so it commutes with the
+//   pooling and the packer folds it into lin_w / lin_b: the shape term then reads the 256 contact channels.)
 //   bias[co]       = mix_b[co] + sum_k mix_wp[co][k] * [offsets|shape][k]     (pare is spatially constant)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void parebias_kernel(const PareArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ float pl[16 * 320];
+  const int shape_c0 = a.C == 320 ? 256 : 0, shape_n = (a.C - shape_c0) * 16;
   __shared__ float pare[112];
   __shared__ float red[10][4];
   for (int i = tid; i < 16 * a.C; i += 256) pl[i] = a.pooled[((size_t)b * 32 + a.part0) * a.C + i];
@@ -158,10 +165,10 @@ __global__ __launch_bounds__(256) void parebias_kernel(const PareArgs a) {
   float part[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) part[k] = 0.f;
-  for (int i = tid; i < 1024; i += 256) {
-    const float x = pl[(i & 15) * a.C + 256 + (i >> 4)];
+  for (int i = tid; i < shape_n; i += 256) {
+    const float x = pl[(i & 15) * a.C + shape_c0 + (i >> 4)];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) part[k] += a.lin_w[k * 1024 + i] * x;
+    for (int k = 0; k < 10; ++k) part[k] += a.lin_w[k * shape_n + i] * x;
   }
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void parebias_kernel(const PareArgs a) {
   }
 }
 hipError_t launch_parebias(const PareArgs& a, hipStream_t s) {
-  if (a.C != 320 || a.out_stride > 256) return hipErrorInvalidValue;
+  if ((a.C != 320 && a.C != 256) || a.out_stride > 256) return hipErrorInvalidValue;
   hipLaunchKernelGGL(parebias_kernel, dim3(a.B), dim3(256), 0, s, a);
   return hipGetLastError();
 }

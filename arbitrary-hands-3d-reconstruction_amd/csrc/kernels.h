@@ -56,9 +56,9 @@ size_t attpool_ws_floats(int B, int C);
 
 // pare bias: pooled [B,32,320] -> per-frame bias row [B, biasP] for the 109->109 mix conv
 struct PareArgs {
-  const float* pooled;   // [B,32,C] (C = 320: 256 contact + 64 shape)
+  const float* pooled;   // [B,32,C] (C = 320: 256 contact + 64 shape; C = 256: contact only, shape conv folded into lin_w)
   const float* lc_w;     // LocallyConnected2d weight [6][256][16]
-  const float* lin_w;    // [10][1024]
+  const float* lin_w;    // [10][(C == 320 ? 64 : 256) * 16]
   const float* lin_b;    // [10]
   const float* mix_wp;   // [109][106] columns of the mix conv that multiply pare
   const float* mix_b;    // [109]

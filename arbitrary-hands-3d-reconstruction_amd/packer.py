@@ -453,19 +453,28 @@ def lower(sd, check=True, point_heads=True):
         heads.center_buf[si], heads.prior_buf[si] = center, prior
     P.release(t0)
     # ---- part branch (acr/model.py:116-166) ---------------------------------------------------------
-    feat = P.buf(128, 128, 320)
+    # The 1x1 shape conv (cam_shape_layers.1.0, acr/model.py:132: no BN, no ReLU) is linear and a part's softmax
+    # weights sum to 1, so it commutes with the attention pooling: pooled_shape = W_cs pooled_contact + b_cs.  It is
+    # folded into the Linear that consumes it (cam_shape_layers.2/3) below; the 256->64 conv over the 128x128 map and
+    # 64 of the 320 pooled channels disappear.
+    feat = P.buf(128, 128, 256)
     P.conv('contact_layers.1.0', x34, [P.folded('contact_layers.1.0', 'contact_layers.1.1')], 3, 1, True, out=feat, cin=34)
-    P.conv('cam_shape_layers.1.0', feat, [P.folded('cam_shape_layers.1.0')], 1, 1, False, out=feat, out_coff=256, cin=256)
-    pooled = P.buf(1, 32, 320)
-    P._op('attpool', 2.0 * 32 * 16384 * 320, kind=_lib.OP_ATTPOOL, in_buf=segm, res_buf=feat, out_buf=pooled, cin=320)
+    pooled = P.buf(1, 32, 256)
+    P._op('attpool', 2.0 * 32 * 16384 * 320 + 2.0 * 128 * 128 * 256 * 64, kind=_lib.OP_ATTPOOL, in_buf=segm, res_buf=feat,
+          out_buf=pooled, cin=256)
+    P.op_info[-1]['name'] = 'attpool(+cam_shape_layers.1.0)'
     P.release(feat)
+    wcs, bcs = P.folded('cam_shape_layers.1.0')
+    wcs = wcs[:, :, 0, 0]                                # [64, 256]
     for si, (side, lc, mix, part0) in enumerate((('l', 2, 4, 16), ('r', 3, 5, 0))):
         wa, wp = mix_w[side]
         bias_buf = P.buf(1, 1, 128, persistent=True)     # one per side: acrmi_point_heads re-reads both
-        P._op('%s.parebias' % side, 0.0, kind=_lib.OP_PAREBIAS, in_buf=pooled, out_buf=bias_buf, cin=320, flags=part0,
+        lw = _np(sd['cam_shape_layers.%d.weight' % lc]).astype(np.float64).reshape(10, 64, 16)    # [k, c, j]
+        lin_w = np.einsum('kcj,cd->kdj', lw, wcs).reshape(10, 256 * 16)                            # [k, c' * 16 + j]
+        lin_b = _np(sd['cam_shape_layers.%d.bias' % lc]).astype(np.float64) + np.einsum('kcj,c->k', lw, bcs)
+        P._op('%s.parebias' % side, 0.0, kind=_lib.OP_PAREBIAS, in_buf=pooled, out_buf=bias_buf, cin=256, flags=part0,
               w_off=P.blob.add(_np(sd['contact_layers.%d.weight' % lc]).reshape(6, 256, 16)),
-              w_off2=P.blob.add(_np(sd['cam_shape_layers.%d.weight' % lc])),
-              b_off2=P.blob.add(_np(sd['cam_shape_layers.%d.bias' % lc])),
+              w_off2=P.blob.add(lin_w), b_off2=P.blob.add(lin_b),
               w_off3=P.blob.add(wp), b_off=P.blob.add(_np(sd['contact_layers.%d.bias' % mix])))
         n0 = len(P.ops)
         P.conv('contact_layers.%d' % mix, camb[side], [padded(wa[:, :3, None, None], np.zeros(109), 128)], 1, 1, False,
