@@ -620,6 +620,9 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     // Cout = 33 with more than one Cin chunk: one regular tile + the 33rd channel on 4x4x1 MFMAs (conv_wino2.inc ODD)
     const bool odd33 = a.Cout == 33 && a.groups == 1 && a.cin8 * 8 > 32 && g_force_cfg != 804;
     const bool nt1 = n32 || a.cin8 * 8 <= 32 || odd33;
+    // 8 < Cin <= 16 with Cout >= 64: two 8-channel chunks give the two-n-tile kernel the two barriers per item its
+    // single-buffered exchange area needs (instead of one n-tile per item and the input transform once per 32 couts)
+    if (!n32 && !odd33 && a.cin8 == 2 && g_force_cfg != 807) return launch_wino2<2, 8, 2>(a, s);
     if (g_force_cfg == 801) return nt1 ? launch_wino2<1, 32, 4>(a, s) : launch_wino2<2, 32, 4>(a, s);
     return nt1 ? launch_wino2<1, 32, 2>(a, s) : launch_wino2<2, 32, 2>(a, s);
   }

@@ -25,6 +25,7 @@ SHAPES = [
     ('b3 256->256 3x3 @16', 256, 256, 16, 16, 3, 1, 1, True),
     ('l1 64->64 3x3 @128', 64, 64, 128, 128, 3, 1, 1, False),
     ('towers 8x64->64 3x3 @64', 512, 512, 64, 64, 3, 1, 8, True),
+    ('segm 16->64 3x3 @256', 16, 64, 256, 256, 3, 1, 1, False),
     ('segm 64->33 3x3 @256', 64, 33, 256, 256, 3, 1, 1, False),
     ('segm 33->33 3x3 @256', 33, 33, 256, 256, 3, 1, 1, False),
     ('contact 34->256 3x3 @128', 34, 256, 128, 128, 3, 1, 1, False),
