@@ -20,7 +20,9 @@ PKG = 'arbitrary-hands-3d-reconstruction_amd'
 SHAPES = [
     # name, cin, cout, H, W, k, stride, groups, residual
     ('b0 32->32 3x3 @128', 32, 32, 128, 128, 3, 1, 1, True),
+    ('b0 32->32 3x3 @128 no residual', 32, 32, 128, 128, 3, 1, 1, False),
     ('b1 64->64 3x3 @64', 64, 64, 64, 64, 3, 1, 1, True),
+    ('b1 64->64 3x3 @64 no residual', 64, 64, 64, 64, 3, 1, 1, False),
     ('b2 128->128 3x3 @32', 128, 128, 32, 32, 3, 1, 1, True),
     ('b3 256->256 3x3 @16', 256, 256, 16, 16, 3, 1, 1, True),
     ('l1 64->64 3x3 @128', 64, 64, 128, 128, 3, 1, 1, False),
