@@ -134,6 +134,9 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   const int c4off = (ltid % (CK / 4)) * 4;
   const int nchunks_l = (cin_pad + CK - 1) / CK;
   const bool idle = a.phase_delay == 8;   // timing ablation: idle loader (wrong results)
+  unsigned want_mask = 0;                 // this lane's element slots that exist (idx < NLOAD)
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) want_mask |= (ltid + i * NLT < NLOAD ? 1u : 0u) << i;
   // request the chunk at (wn, cn0) and advance.  The loads are issued unconditionally (past the last chunk they
   // re-read the previous addresses): behind a branch hipcc cannot count the loads in flight any more and makes
   // every later wait a vmcnt(0), which would serialise the two register sets again.
@@ -182,7 +185,16 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
     const int c = st.c;
     const bool cok = c < a.Cin;
     const bool ragged_c = cok && (c + 3 >= a.Cin);   // this float4 straddles Cin
-    if (!idle) {
+    // Interior tiles of full-channel chunks (the common case) need no masking at all: a wave-uniform test sends them
+    // down a path with no VALU per element - a loader wave's VALU only issues in the gaps of its SIMD's MFMA stream.
+    const bool plain = __builtin_amdgcn_ballot_w64(!cok || ragged_c || (st.pixok & want_mask) != want_mask) == 0;
+    if (!idle && plain) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int idx = ltid + i * NLT;
+        if (idx < NLOAD) *reinterpret_cast<f32x4*>(dst + (idx / (CK / 4)) * CP + c4off) = st.v[i];
+      }
+    } else if (!idle) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int idx = ltid + i * NLT;
