@@ -15,8 +15,9 @@ using namespace acrmi;
 // ---- op dependencies and stream lanes ----------------------------------------------------------------
 constexpr int MAX_LANES = 8;
 // ACRMI_OPT_LANES = 0: measured on MI355X (tools/lanes_check.py) - batch 1: 6.97 ms on one stream, 4.63 on four;
-// batch 64: 46.9 ms on one, 45.6 on two (the second lane fills the tails and pipeline fills of the first), 45.8 on three
-constexpr int AUTO_LANES_SMALL = 4, AUTO_LANES_LARGE = 2, AUTO_SMALL_BATCH = 16;
+// batch 32: 23.2 / 22.5 / 22.2 ms on one / two / four; batch 64: 46.9 ms on one, 45.6 on two (the second lane fills the
+// tails and pipeline fills of the first), 45.8 on three
+constexpr int AUTO_LANES_SMALL = 4, AUTO_LANES_LARGE = 2, AUTO_SMALL_BATCH = 32;
 struct Schedule {
   std::vector<int> order;               // active op indices, program order (a topological order)
   std::vector<std::vector<int>> deps;   // per op: earlier ops it must wait for (RAW / WAR / WAW on buffer ids)

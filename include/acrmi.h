@@ -200,7 +200,7 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
 /* ACRMI_OPT_LANES (0..8, default 0): the program's independent chains (HRNet branches, head towers, segm and part
  * heads; found from the ops' buffer reads/writes) run on that many HIP streams: lane 0 is the caller's stream, the
  * others fork from it at the start of a call and join it before the call's decode, so the caller still sees one
- * stream-ordered operation.  0 = chosen by batch size (4 lanes up to 16 frames, 2 above), 1 = single stream.
+ * stream-ordered operation.  0 = chosen by batch size (4 lanes up to 32 frames, 2 above), 1 = single stream.
  * Same kernels, bit-identical results. */
 #define ACRMI_OPT_LANES 2
 int acrmi_set_option(acrmi_ctx* ctx, int option, int value);
