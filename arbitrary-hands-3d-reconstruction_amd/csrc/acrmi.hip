@@ -49,7 +49,6 @@ struct acrmi_ctx {
   hipStream_t lanes[MAX_LANES] = {};
   hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {};
   std::vector<hipEvent_t> op_ev;
-  unsigned long long tick = 0;
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
   std::vector<float*> mano_allocs;
