@@ -8,7 +8,8 @@ LIB_PATH = os.environ.get('ACRMI_LIB') or os.path.join(HERE, 'libacrmi.so')   # 
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS = range(1, 10)
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
-OPT_POINT_HEADS, OPT_LANES = 1, 2
+OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF = 1, 2, 3, 4, 5, 6
+VERSION = 200
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
 E_INVAL, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
@@ -40,7 +41,8 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
            'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
-           'acrmi_set_option', 'acrmi_point_heads']
+           'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
+           'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather']
 
 _lib = None
 
@@ -72,7 +74,7 @@ def lib():
     L.acrmi_buffer_ptr.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.acrmi_buffer_ptr.restype = vp
     L.acrmi_decode.argtypes = [vp, i32, f32p, vp]
-    L.acrmi_decode_maps.argtypes = [f32p, f32p, i32, f32p, f32p, i32, f32p, f32p, i32, i32, f32p, vp]
+    L.acrmi_decode_maps.argtypes = [f32p, f32p, i32, f32p, f32p, i32, f32p, f32p, i32, i32, C.c_float, f32p, vp]
     L.acrmi_mano.argtypes = [vp, f32p, i32, f32p, i32, vp, i32, i32, f32p, f32p, f32p, f32p, i32, f32p, f32p, f32p,
                              f32p, vp]
     L.acrmi_forward.argtypes = [vp, u8p, i32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp]
@@ -89,6 +91,13 @@ def lib():
     L.acrmi_cam_trans.argtypes = [f32p, f32p, i32, C.c_float, C.c_float, f32p, vp]
     L.acrmi_set_option.argtypes = [vp, i32, i32]
     L.acrmi_point_heads.argtypes = [vp, i32, vp]
+    L.acrmi_set_option_f.argtypes = [vp, i32, C.c_float]
+    L.acrmi_smooth.argtypes = [vp, f32p, i32, vp]
+    L.acrmi_smooth_reset.argtypes = [vp, vp]
+    L.acrmi_comm_unique_id.argtypes = [vp]
+    L.acrmi_comm_init.argtypes = [vp, i32, i32, vp]
+    L.acrmi_comm_destroy.argtypes = [vp]
+    L.acrmi_allgather.argtypes = [vp, vp, f32p, f32p, C.c_size_t, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr'):

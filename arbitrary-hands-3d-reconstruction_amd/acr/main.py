@@ -28,10 +28,12 @@ class ACR(object):
         for k, v in vars(a).items():
             setattr(self, k, v)
         logging.basicConfig(level=logging.INFO)
-        if self.temporal_optimization:
-            self.filter_dict = {0: create_OneEuroFilter(a.smooth_coeff), 1: create_OneEuroFilter(a.smooth_coeff)}
         self._args = a
+        self._device = device
         self._build_model_(state_dict, mano_tables, device, max_batch)
+        if self.temporal_optimization:
+            # acr/main.py:45-47: one filter set per hand type; the state lives in the engine's context
+            self.filter_dict = create_OneEuroFilter(a.smooth_coeff, engine=self.model.engine())
 
     def _build_model_(self, state_dict, mano_tables, device, max_batch):
         """acr/main.py:57-63"""
@@ -43,7 +45,7 @@ class ACR(object):
                 model = load_model(self.model_path, model, prefix='module.', drop_prefix='', fix_loaded=False)
             self.model = model.cuda(device)
             self.mano_regression = MANOWrapper(mano_root=self.mano_root, tables=mano_tables, device=device,
-                                               engine=self.model.engine())
+                                               engine=self.model.engine()).bind_model(self.model)
 
     @torch.no_grad()
     def process_results(self, outputs):
@@ -52,10 +54,13 @@ class ACR(object):
             pd = outputs['params_dict']
             if len(pd['poses']) != 2:
                 raise ValueError('temporal optimisation expects exactly one frame (2 rows), as acr/main.py:77 asserts')
-            for sid, flag in enumerate(outputs['detection_flag_cache']):
-                if flag:                                        # row index == hand type at batch 1
-                    p, b = smooth_results(self.filter_dict[sid], pd['poses'][sid].cpu(), pd['betas'][sid].cpu())
-                    pd['poses'][sid], pd['betas'][sid] = p.to(pd['poses'].device), b.to(pd['betas'].device)
+            # rows of a one-frame batch are [left, right] = the slot order: smooth the slots on the device and
+            # refresh the rows the MANO stage reads (acr/main.py:69-83)
+            from .. import _lib as S
+            slots = smooth_results(self.filter_dict, outputs['slots'])
+            pd['poses'].copy_(slots[0, :, S.SLOT_POSES:S.SLOT_POSES + 48])
+            pd['betas'].copy_(slots[0, :, S.SLOT_BETAS:S.SLOT_BETAS + 10])
+            pd['global_orient'], pd['hand_pose'] = pd['poses'][:, :3].contiguous(), pd['poses'][:, 3:].contiguous()
         outputs = self.mano_regression(outputs, outputs['meta_data'])
         reorganize_idx = outputs['reorganize_idx'].cpu().numpy()
         results = reorganize_results(outputs, outputs['meta_data']['imgpath'], reorganize_idx)
@@ -64,7 +69,7 @@ class ACR(object):
     @torch.no_grad()
     def single_image_forward(self, bgr_frame, path):
         """acr/main.py:126-141"""
-        meta = img_preprocess(bgr_frame, path, input_size=self.input_size, single_img_input=True)
+        meta = img_preprocess(bgr_frame, path, input_size=self.input_size, single_img_input=True, device=self._device)
         ds_org, imgpath_org = get_remove_keys(meta, keys=['data_set', 'imgpath'])
         meta['batch_ids'] = torch.arange(len(meta['image']))
         outputs = self.model(meta, **self.demo_cfg)
@@ -101,12 +106,18 @@ class ACR(object):
         if offsets is None:
             offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(B, 1)
         eng.set_point_heads(point_heads)
+        eng.set_temporal(bool(self.temporal_optimization))     # frames of the batch = one video stream, in order
         try:
             out = eng.forward(rgb_u8_frames, offsets=offsets, project=True)
         finally:
             eng.set_point_heads(False)
+            eng.set_temporal(False)
+        # cam_trans for every slot (acr/utils.py:399-412): the device least-squares kernel on [B*2] hands
+        from .. import ops
+        out['cam_trans'] = ops.cam_trans(out['joints'].view(-1, 21, 3), out['pj2d'].view(-1, 21, 2),
+                                         focal_length=self.focal_length).view(B, 2, 3)
         slots = out['slots'].cpu().numpy()
-        host = {k: out[k].cpu().numpy() for k in ('verts', 'joints', 'pj2d', 'pj2d_org')}
+        host = {k: out[k].cpu().numpy() for k in ('verts', 'joints', 'pj2d', 'pj2d_org', 'cam_trans')}
         from .. import _lib as S
         results = {}
         for b, path in enumerate(paths):
@@ -115,6 +126,7 @@ class ACR(object):
                 if slots[b, h, S.SLOT_FLAG] > 0.5:
                     s = slots[b, h]
                     hands.append({'cam': s[S.SLOT_CAM:S.SLOT_CAM + 3].astype(np.float16),
+                                  'cam_trans': host['cam_trans'][b, h].astype(np.float16),
                                   'poses': s[S.SLOT_POSES:S.SLOT_POSES + 48].astype(np.float16),
                                   'betas': s[S.SLOT_BETAS:S.SLOT_BETAS + 10].astype(np.float16),
                                   'j3d': host['joints'][b, h].astype(np.float16),

@@ -1,5 +1,5 @@
 """MANOWrapper (acr/mano_wrapper.py:15-50): two ManoLayers (left shapedirs x-flipped), one fused HIP
-launch for all rows, projection fused into the kernel epilogue; cam_trans stays on the host."""
+launch for all rows, projection fused into the kernel epilogue; cam_trans from the device least-squares kernel."""
 import torch
 
 from ..config import args
@@ -17,10 +17,20 @@ class MANOWrapper(object):
             'r': ManoLayer(side='right', tables=None if tables is None else tables['right'], **kw),
             'l': ManoLayer(side='left', tables=None if tables is None else tables['left'], **kw)}
         self.mano_layer['l'].th_shapedirs[:, 0, :] *= -1          # acr/mano_wrapper.py:35
+        self._model = None            # acr.model.ACR whose current engine is used (set by bind_model)
         self._engine = engine or shared_engine(device)
         for lay in self.mano_layer.values():
             lay.sync(self._engine)
         self.center_idx = cidx
+
+    def bind_model(self, model):
+        """Follow `model.engine()` instead of a fixed context: a checkpoint reload replaces the model's engine (the
+        new one adopts these MANO tables), and this wrapper must not keep launching on the retired one."""
+        self._model = model
+        return self
+
+    def engine(self):
+        return self._model.engine() if self._model is not None else self._engine
 
     def cuda(self, device=None):
         return self
@@ -37,12 +47,12 @@ class MANOWrapper(object):
         side = torch.cat((torch.zeros(L), torch.ones(R))).to(torch.int32)
         outputs['output_hand_type'] = side.to(dev)
         offsets = meta_data.get('offsets') if meta_data is not None else None
-        verts, joints, _, extra = self._engine.mano(pd['poses'][:L + R], pd['betas'][:L + R], side,
+        verts, joints, _, extra = self.engine().mano(pd['poses'][:L + R], pd['betas'][:L + R], side,
                                                    center_idx=self.center_idx, cam=pd['cam'][:L + R], offsets=offsets)
         outputs.update({'verts': verts, 'j3d': joints, 'verts_camed': extra['verts_camed'], 'pj2d': extra['pj2d']})
         if 'pj2d_org' in extra:
             outputs['pj2d_org'] = extra['pj2d_org']
-        # per-hand camera translation: host-side least squares (acr/utils.py:430-472), render-only
+        # per-hand camera translation: the reference's closed-form least squares (acr/utils.py:430-472) on the device
         outputs['cam_trans'] = estimate_translation(joints, extra['pj2d'], focal_length=args().focal_length).to(dev)
         return outputs
 

@@ -15,7 +15,8 @@ from .result_parser import ResultParser, rows_from_slots
 
 class ACR(object):
     def __init__(self, device=0, max_batch=1, **kwargs):
-        validate(args())
+        self._args = validate(args())
+        self._retired = None
         self._result_parser = ResultParser()
         self.params_num = self._result_parser.params_num
         self._sd = OrderedDict()
@@ -50,7 +51,8 @@ class ACR(object):
                     raise ValueError('size mismatch for %s: %s vs %s' % (k, tuple(t.shape), tuple(self._sd[k].shape)))
                 self._sd[k] = t.to(self._sd[k].dtype).clone()
         self._loaded = True
-        self._engine = None            # re-pack on next use
+        if self._engine is not None:   # re-pack on next use; the new context adopts the MANO tables / options
+            self._retired, self._engine = self._engine, None
         return missing, unexpected
 
     def eval(self):
@@ -72,9 +74,19 @@ class ACR(object):
         return self.cuda(device)
 
     def engine(self, min_batch=1):
+        """The resident context.  A checkpoint reload builds a new one that adopts the old one's MANO tables and
+        options, so wrappers holding the model (MANOWrapper) keep working."""
         if self._engine is None:
-            self._engine = Engine(self._device)
-            self._engine.load_state_dict(self._sd, max_batch=max(self._max_batch, min_batch))
+            eng = Engine(self._device)
+            eng.load_state_dict(self._sd, max_batch=max(self._max_batch, min_batch))
+            a = self._args
+            eng.set_conf_thresh(a.centermap_conf_thresh)          # CenterMap.conf_thresh (acr/result_parser.py:198-205)
+            eng.set_center_idx(a.align_idx if a.mano_mesh_root_align else None)
+            if self._retired is not None:
+                eng.adopt(self._retired)
+                self._retired.close()
+                self._retired = None
+            self._engine = eng
         else:
             self._engine.ensure_batch(min_batch)
         return self._engine

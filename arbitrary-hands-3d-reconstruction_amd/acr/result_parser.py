@@ -71,6 +71,7 @@ class ResultParser(object):
     def __init__(self):
         a = args()
         self.map_size = a.centermap_size
+        self.conf_thresh = a.centermap_conf_thresh          # CenterMap.conf_thresh (acr/result_parser.py:198-205)
         self.part_name = ['cam', 'global_orient', 'hand_pose', 'betas']
         self.part_idx = [a.cam_dim, a.rot_dim, (a.mano_theta_num - 1) * a.rot_dim, 10]
         self.kps_num = 21
@@ -90,7 +91,7 @@ class ResultParser(object):
             m = {k: ops.to_nhwc(outputs[k], device=outputs[k].device) for k in
                  ('l_center_map', 'r_center_map', 'l_params_maps', 'r_params_maps', 'l_prior_maps', 'r_prior_maps')}
             slots = ops.decode_maps(m['l_center_map'], m['r_center_map'], m['l_params_maps'], m['r_params_maps'],
-                                    m['l_prior_maps'], m['r_prior_maps'])
+                                    m['l_prior_maps'], m['r_prior_maps'], conf_thresh=self.conf_thresh)
             outputs['slots'] = slots
         outputs.update(rows_from_slots(slots, meta_data, self.map_size))
         return outputs, meta_data

@@ -1,6 +1,6 @@
-"""Host glue of the ACR path with the reference's function names (acr/utils.py): checkpoint loading,
-pre-processing, result packaging, temporal smoothing, camera translation.  None of this is on the
-conv roofline; it runs on the host (numpy/torch-CPU) exactly where the reference runs it on the host.
+"""Host glue of the ACR path with the reference's function names (acr/utils.py): checkpoint loading, result
+packaging, and thin wrappers that send pre-processing, temporal smoothing and camera translation to their HIP
+kernels (the reference runs those three on the host; here they stay on the device next to the data).
 """
 import logging
 import os
@@ -8,7 +8,6 @@ import pickle
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 
 # ---- checkpoint (acr/utils.py:1106-1168) -----------------------------------------------------------
@@ -43,7 +42,8 @@ def load_model(path, model, prefix='module.', drop_prefix='', optimizer=None, **
 # ---- pre-processing (acr/utils.py:1276-1337) ---------------------------------------------------------
 def compute_paddings_to_reach_aspect_ratio(shape, ratio=1.0):
     """imgaug.augmenters.size.compute_paddings_to_reach_aspect_ratio (imgaug 0.4.0) restated:
-    pad the shorter side symmetrically (extra pixel goes to bottom/right) -> (top, right, bottom, left)."""
+    pad the shorter side symmetrically (extra pixel goes to bottom/right) -> (top, right, bottom, left).
+    (Geometry only; the device kernel computes the same numbers in acrmi_preprocess.)"""
     h, w = shape[:2]
     top = right = bottom = left = 0
     if w / float(h) < ratio:                     # too tall -> pad width
@@ -55,30 +55,26 @@ def compute_paddings_to_reach_aspect_ratio(shape, ratio=1.0):
     return top, right, bottom, left
 
 
-def image_pad_white_bg(image, pad_trbl=None, pad_ratio=1., pad_cval=255):
-    if pad_trbl is None:
-        pad_trbl = compute_paddings_to_reach_aspect_ratio(image.shape, pad_ratio)
-    t, r, b, l = pad_trbl
-    out = np.pad(image, ((t, b), (l, r), (0, 0)), mode='constant', constant_values=pad_cval)
-    return out, np.array([*out.shape[:2], 0, 0, 0, 0, *pad_trbl])
-
-
-def resize_cubic(image_u8, size):
-    """Stand-in for cv2.resize(..., INTER_CUBIC) (cv2 is absent here): bicubic, a = -0.75, half-pixel
-    centres, no antialias - torch's kernel is the same family as OpenCV's.  Parity with cv2 is unpinned."""
-    x = torch.from_numpy(np.ascontiguousarray(image_u8)).permute(2, 0, 1)[None].float()
-    y = F.interpolate(x, size=(size, size), mode='bicubic', align_corners=False)
-    return y.round().clamp(0, 255).to(torch.uint8)[0].permute(1, 2, 0).contiguous()
-
-
-def img_preprocess(image, imgpath=None, input_size=512, single_img_input=False, bbox=None):
-    """BGR frame -> {'image': uint8 [1,512,512,3] RGB, 'offsets': [1,10]} (acr/utils.py:1315-1337)."""
-    image = np.ascontiguousarray(image[:, :, ::-1])
-    padded, offsets = image_pad_white_bg(image)
-    img = resize_cubic(padded, input_size)
-    offsets = torch.from_numpy(offsets).float()
-    if single_img_input:
-        img, offsets = img.unsqueeze(0).contiguous(), offsets.unsqueeze(0).contiguous()
+def img_preprocess(image, imgpath=None, input_size=512, single_img_input=False, bbox=None, device=0):
+    """BGR frame (numpy HxWx3 uint8, or a uint8 tensor) -> {'image': uint8 [1,512,512,3] RGB, 'offsets': [1,10]}
+    (acr/utils.py:1315-1337).  The white pad + cv2.resize(INTER_CUBIC) run in the HIP pre-processing kernel
+    (acrmi_preprocess: OpenCV's uint8 fixed-point cubic restated bit for bit); the image stays in HBM."""
+    if input_size != 512:
+        raise ValueError('only input_size=512 is implemented')
+    if bbox is not None:
+        raise ValueError('bbox cropping is not used by the demo path (acr/main.py:130) and is not implemented')
+    frame = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image))
+    if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[-1] != 3:
+        raise ValueError('frame must be uint8 HxWx3 BGR')
+    if not frame.is_cuda:
+        if not torch.cuda.is_available():
+            from .. import _lib
+            raise _lib.AcrmiError('no GPU visible: pre-processing runs in the HIP kernel (no CPU fallback)')
+        frame = frame.to(torch.device('cuda', device))
+    data = img_preprocess_gpu(frame[None], None)
+    img, offsets = data['image'], data['offsets']
+    if not single_img_input:
+        img, offsets = img[0], offsets[0]
     data = {'image': img, 'offsets': offsets, 'data_set': 'internet'}
     if imgpath is not None:
         data.update({'imgpath': imgpath, 'name': os.path.basename(imgpath)})
@@ -86,9 +82,9 @@ def img_preprocess(image, imgpath=None, input_size=512, single_img_input=False, 
 
 
 def img_preprocess_gpu(bgr_frames, imgpaths=None):
-    """Batched device pre-processing (SURVEY.md §8f-1): uint8 BGR frames [n,H,W,3] already in HBM ->
-    {'image': uint8 RGB [n,512,512,3] (device), 'offsets': [n,10], 'batch_ids': [n]}.  Same arithmetic as
-    img_preprocess above (white square pad, bicubic a=-0.75), one HIP kernel, no host round trip."""
+    """Batched device pre-processing (SURVEY.md 8f-1): uint8 BGR frames [n,H,W,3] already in HBM ->
+    {'image': uint8 RGB [n,512,512,3] (device), 'offsets': [n,10], 'batch_ids': [n]}: one HIP kernel, no host
+    round trip."""
     from .. import ops
     img, offsets = ops.preprocess(bgr_frames)
     data = {'image': img, 'offsets': offsets, 'data_set': 'internet', 'batch_ids': torch.arange(img.shape[0])}
@@ -144,117 +140,38 @@ def save_results(results, path):
 
 
 # ---- camera translation (acr/utils.py:430-519) -----------------------------------------------------------
-def estimate_translation_np(joints_3d, joints_2d, joints_conf, focal_length=600, img_size=np.array([512., 512.])):
-    """Weighted least squares for the translation that best projects joints_3d onto joints_2d
-    (acr/utils.py:430-472) - the closed form the reference falls back to when cv2.solvePnPRansac fails."""
-    n = joints_3d.shape[0]
-    f = np.array([focal_length, focal_length], np.float64)
-    center = np.asarray(img_size, np.float64) / 2.
-    Z = np.reshape(np.tile(joints_3d[:, 2], (2, 1)).T, -1)
-    XY = np.reshape(joints_3d[:, 0:2], -1)
-    O = np.tile(center, n)
-    Fv = np.tile(f, n)
-    w2 = np.reshape(np.tile(np.sqrt(joints_conf), (2, 1)).T, -1)
-    Q = np.array([Fv * np.tile(np.array([1, 0]), n), Fv * np.tile(np.array([0, 1]), n), O - np.reshape(joints_2d, -1)]).T
-    c = (np.reshape(joints_2d, -1) - O) * Z - Fv * XY
-    W = np.diagflat(w2)
-    Q, c = np.dot(W, Q), np.dot(W, c)
-    return np.linalg.solve(np.dot(Q.T, Q), np.dot(Q.T, c))
-
-
 def estimate_translation(joints_3d, pj2d, focal_length=600, img_size=np.array([512., 512.])):
     """Per-hand cam_trans (acr/utils.py:399-412,474-519): 2D targets are (pj2d+1)*256.
-    The reference tries cv2 EPnP+RANSAC first (non-deterministic, render-only); this build always takes
-    the reference's deterministic least-squares branch - on the device (acrmi_cam_trans) for device tensors,
-    with the numpy restatement below for host tensors."""
-    if joints_3d.is_cuda:
-        from .. import ops
-        return ops.cam_trans(joints_3d, pj2d, focal_length=focal_length, img_size=float(np.asarray(img_size).reshape(-1)[0]))
-    j3 = joints_3d.detach().cpu().numpy().astype(np.float64)
-    j2 = (pj2d.detach().cpu().numpy().astype(np.float64) + 1) * 256
-    trans = np.zeros((j3.shape[0], 3))
-    for i in range(j3.shape[0]):
-        conf = np.ones(j3.shape[1], np.float32)
-        trans[i] = estimate_translation_np(j3[i], j2[i], conf, focal_length=focal_length, img_size=img_size)
-    return torch.from_numpy(trans).float()
+    The reference tries cv2 EPnP+RANSAC first (non-deterministic, render-only); this build always takes the
+    reference's deterministic least-squares branch (acr/utils.py:430-472), on the device (acrmi_cam_trans)."""
+    from .. import ops
+    return ops.cam_trans(joints_3d, pj2d, focal_length=focal_length, img_size=float(np.asarray(img_size).reshape(-1)[0]))
 
 
 # ---- temporal smoothing (acr/utils.py:1466-1527) -----------------------------------------------------------
-class LowPassFilter(object):
-    def __init__(self):
-        self.prev_raw_value = None
-        self.prev_filtered_value = None
+class DeviceOneEuro(object):
+    """The reference keeps one dict of OneEuroFilters per hand type on the host (acr/main.py:45-47) and filters row by
+    row with a D2H/H2D per frame.  Here the filter state of the stream lives in the engine's context and
+    `acrmi_smooth` updates both hands' poses/betas in one launch between decode and MANO."""
 
-    def process(self, value, alpha):
-        s = value if self.prev_raw_value is None else alpha * value + (1.0 - alpha) * self.prev_filtered_value
-        self.prev_raw_value = value
-        self.prev_filtered_value = s
-        return s
+    def __init__(self, engine, smooth_coeff):
+        self.engine, self.smooth_coeff = engine, float(smooth_coeff)
+        engine.set_temporal(False, smooth_coeff=smooth_coeff)
+        engine.smooth_reset()
 
-
-class OneEuroFilter(object):
-    def __init__(self, mincutoff=1.0, beta=0.0, dcutoff=1.0, freq=30):
-        self.freq, self.mincutoff, self.beta, self.dcutoff = freq, mincutoff, beta, dcutoff
-        self.x_filter, self.dx_filter = LowPassFilter(), LowPassFilter()
-
-    def compute_alpha(self, cutoff):
-        te = 1.0 / self.freq
-        tau = 1.0 / (2 * np.pi * cutoff)
-        return 1.0 / (1.0 + tau / te)
-
-    def process(self, x):
-        prev_x = self.x_filter.prev_raw_value
-        dx = 0.0 if prev_x is None else (x - prev_x) * self.freq
-        edx = self.dx_filter.process(dx, self.compute_alpha(self.dcutoff))
-        cutoff = self.mincutoff + self.beta * (torch.abs(edx) if isinstance(edx, torch.Tensor) else np.abs(edx))
-        return self.x_filter.process(x, self.compute_alpha(cutoff))
+    def process_slots(self, slots):
+        return self.engine.smooth(slots)
 
 
-def create_OneEuroFilter(smooth_coeff):
-    return {'poses': OneEuroFilter(smooth_coeff, 0.7), 'betas': OneEuroFilter(0.6, 0.7),
-            'global_orient': OneEuroFilter(smooth_coeff, 0.7)}
+def create_OneEuroFilter(smooth_coeff, engine=None):
+    """acr/utils.py:1472-1473.  With an engine: the device filter set; the per-filter parameters (poses / global
+    orient: mincutoff = smooth_coeff, betas: 0.6; beta 0.7) are fixed inside acrmi_smooth."""
+    if engine is None:
+        raise ValueError('create_OneEuroFilter needs the engine whose context holds the filter state')
+    return DeviceOneEuro(engine, smooth_coeff)
 
 
-def _rodrigues_host(aa):
-    """mano/manolayer.py:423-434 on one axis-angle vector (host tensor) -> [3,3]."""
-    angle = torch.norm(aa + 1e-8)
-    axis = aa / angle
-    half = angle * 0.5
-    q = torch.cat([torch.cos(half)[None], torch.sin(half) * axis])
-    q = q / q.norm()
-    w, x, y, z = q
-    return torch.stack([w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
-                        2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
-                        2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z]).view(3, 3)
-
-
-def _rotmat_to_aa_host(R):
-    """acr/utils.py:334-360 on one matrix (via quaternion, NaN -> 0)."""
-    t = R.t()
-    if t[2, 2] < 1e-6:
-        if t[0, 0] > t[1, 1]:
-            tr = 1 + t[0, 0] - t[1, 1] - t[2, 2]
-            q = torch.stack([t[1, 2] - t[2, 1], tr, t[0, 1] + t[1, 0], t[2, 0] + t[0, 2]])
-        else:
-            tr = 1 - t[0, 0] + t[1, 1] - t[2, 2]
-            q = torch.stack([t[2, 0] - t[0, 2], t[0, 1] + t[1, 0], tr, t[1, 2] + t[2, 1]])
-    elif t[0, 0] < -t[1, 1]:
-        tr = 1 - t[0, 0] - t[1, 1] + t[2, 2]
-        q = torch.stack([t[0, 1] - t[1, 0], t[2, 0] + t[0, 2], t[1, 2] + t[2, 1], tr])
-    else:
-        tr = 1 + t[0, 0] + t[1, 1] + t[2, 2]
-        q = torch.stack([tr, t[1, 2] - t[2, 1], t[2, 0] - t[0, 2], t[0, 1] - t[1, 0]])
-    q = q / torch.sqrt(tr) * 0.5
-    s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3]
-    s = torch.sqrt(s2)
-    two_theta = 2.0 * (torch.atan2(-s, -q[0]) if q[0] < 0 else torch.atan2(s, q[0]))
-    k = two_theta / s if s2 > 0 else torch.tensor(2.0)
-    aa = q[1:] * k
-    return torch.where(torch.isnan(aa), torch.zeros_like(aa), aa)
-
-
-def smooth_results(filters, body_pose=None, body_shape=None):
-    """acr/utils.py:1475-1479: global orient filtered in rotation-matrix space, fingers/betas directly."""
-    rot = filters['global_orient'].process(_rodrigues_host(body_pose[:3]))
-    body_pose = torch.cat([_rotmat_to_aa_host(rot), filters['poses'].process(body_pose[3:])], 0)
-    return body_pose, filters['betas'].process(body_shape)
+def smooth_results(filters, slots):
+    """acr/utils.py:1475-1479 over a [B,2,176] slot tensor (in place): global orient filtered in rotation-matrix
+    space, fingers and betas directly, only for hands whose detection flag is set."""
+    return filters.process_slots(slots)

@@ -74,6 +74,13 @@ def validate(ns):
         raise ValueError('only centermap_size=64, input_size=512, head_block_num=2, offset_mode=concat are implemented')
     if ns.merge_mano_camera_head or ns.perspective_proj:
         raise ValueError('merge_mano_camera_head / perspective_proj are not implemented (acr/model.py:85-88)')
+    if list(ns.kernel_sizes) != [5]:
+        # CenterMap's NMS window (acr/result_parser.py:199,207-216): the decode kernel implements the 5x5 pool only
+        raise ValueError('kernel_sizes=%r: only the 5x5 center NMS (kernel_sizes=[5]) is implemented' % (ns.kernel_sizes,))
+    if ns.max_hand != 2:
+        raise ValueError('max_hand=%r: one left and one right hand per frame (top-1 per center map) is implemented' % ns.max_hand)
+    if not (isinstance(ns.align_idx, int) and 0 <= ns.align_idx <= 20):
+        raise ValueError('align_idx must be a joint index 0..20')
     if ns.model_precision not in ('fp32',):
         raise ValueError('model_precision %r: this build computes in fp32 only' % ns.model_precision)
     return ns

@@ -2,6 +2,9 @@
 #include "../../include/acrmi.h"
 #include "kernels.h"
 
+#include <dlfcn.h>
+
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
@@ -51,7 +54,35 @@ struct acrmi_ctx {
   std::vector<hipEvent_t> op_ev;
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
-  std::vector<float*> mano_allocs;
+  float* mano_allocs[2][6] = {};
+  // options the reference reads from its config (acr/config.py): centermap_conf_thresh (acr/result_parser.py:241),
+  // align_idx / mano_mesh_root_align (acr/mano_wrapper.py:19-33), -t temporal_optimization + smooth_coeff (acr/main.py:45-47)
+  float conf_thresh = 0.35f;
+  int center_idx = 9;           // < 0: no root alignment
+  bool temporal = false;
+  float smooth_coeff = 4.0f;
+  float* smooth_state = nullptr;   // [2][3][64] floats + 2 ints (One-Euro state of one video stream)
+  // multi-GPU: RCCL communicator created by acrmi_comm_init
+  void* comm = nullptr;
+  int comm_ranks = 0;
+};
+
+// Every entry point runs on the context's device and leaves the caller's current device as it found it (a process
+// may hold contexts on several GPUs).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
 };
 
 static std::string g_err;
@@ -65,6 +96,9 @@ static int fail(acrmi_ctx* c, int code, const char* fmt, ...) {
   if (c) c->err = buf; else g_err = buf;
   return code;
 }
+#define ON_DEVICE(c)                                                                                   \
+  DeviceGuard guard_((c)->device);                                                                     \
+  if (guard_.err != hipSuccess) return fail(c, ACRMI_EHIP, "hipSetDevice(%d): %s", (c)->device, hipGetErrorString(guard_.err))
 #define HIPCHK(c, expr)                                                                      \
   do {                                                                                       \
     hipError_t e_ = (expr);                                                                  \
@@ -84,8 +118,10 @@ int acrmi_create(acrmi_ctx** out, int device) {
   if (e != hipSuccess || n <= 0)
     return fail(nullptr, ACRMI_EHIP, "acrmi_create: no HIP device (%s)", hipGetErrorString(e));
   if (device < 0 || device >= n) return fail(nullptr, ACRMI_EINVAL, "acrmi_create: device %d of %d", device, n);
-  e = hipSetDevice(device);
-  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+  {
+    DeviceGuard g(device);      // validates the device; the caller's current device is restored
+    if (g.err != hipSuccess) return fail(nullptr, ACRMI_EHIP, "hipSetDevice: %s", hipGetErrorString(g.err));
+  }
   acrmi_ctx* c = new acrmi_ctx();
   c->device = device;
   *out = c;
@@ -108,9 +144,12 @@ static void free_program(acrmi_ctx* c) {
   c->have_program = false;
 }
 
+static void comm_destroy(acrmi_ctx* c);
+
 void acrmi_destroy(acrmi_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceGuard guard_(c->device);
+  comm_destroy(c);
   free_program(c);
   for (int l = 0; l < MAX_LANES; ++l) {
     if (c->lanes[l]) (void)hipStreamDestroy(c->lanes[l]);
@@ -118,13 +157,16 @@ void acrmi_destroy(acrmi_ctx* c) {
   }
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   if (c->weights) (void)hipFree(c->weights);
-  for (float* p : c->mano_allocs) (void)hipFree(p);
+  if (c->smooth_state) (void)hipFree(c->smooth_state);
+  for (auto& side : c->mano_allocs)
+    for (float* p : side)
+      if (p) (void)hipFree(p);
   delete c;
 }
 
 int acrmi_load_weights(acrmi_ctx* c, const float* blob, size_t n) {
   if (!c || !blob || n == 0) return fail(c, ACRMI_EINVAL, "acrmi_load_weights: bad arguments");
-  HIPCHK(c, hipSetDevice(c->device));
+  ON_DEVICE(c);
   if (c->weights) (void)hipFree(c->weights);
   c->weights = nullptr;
   HIPCHK(c, hipMalloc(&c->weights, n * sizeof(float)));
@@ -226,7 +268,7 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       p.p109 = ptr(op.res_buf); p.p109_cs = desc(op.res_buf).cs;
       p.prior = ptr(h.prior_buf[side]); p.prior_cs = desc(h.prior_buf[side]).cs;
       p.final_ = ptr(op.out_buf); p.final_cs = desc(op.out_buf).cs;
-      p.picks = c->picks; p.side = side; p.B = B;
+      p.picks = c->picks; p.side = side; p.B = B; p.thresh = c->conf_thresh;
       HIPCHK(c, launch_point_heads(p, s));
       return ACRMI_OK;
     }
@@ -330,7 +372,110 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   if (!c || !bufs || !ops || !heads || n_bufs <= 0 || n_ops <= 0 || max_batch <= 0)
     return fail(c, ACRMI_EINVAL, "acrmi_set_program: bad arguments");
   if (!c->weights) return fail(c, ACRMI_ESTATE, "acrmi_set_program: load weights first");
-  HIPCHK(c, hipSetDevice(c->device));
+  ON_DEVICE(c);
+  // ---- validate before anything is allocated: a malformed program must fail here, not fault on the device
+  for (int i = 0; i < n_bufs; ++i) {
+    const auto& d = bufs[i];
+    if (d.h <= 0 || d.w <= 0 || d.cs <= 0 || d.cs % 4) return fail(c, ACRMI_EINVAL, "buffer %d: bad geometry", i);
+  }
+  auto buf_ok = [&](int id) { return id >= 0 && id < n_bufs; };
+  auto w_ok = [&](long long off, long long n) { return off >= 0 && n >= 0 && (unsigned long long)(off + n) <= c->n_weights; };
+  {
+    const int hb[8] = {heads->center_buf[0], heads->center_buf[1], heads->params_buf[0], heads->params_buf[1],
+                       heads->prior_buf[0], heads->prior_buf[1], heads->segm_buf, heads->backbone_buf};
+    for (int id : hb)
+      if (!buf_ok(id)) return fail(c, ACRMI_EINVAL, "head layout references buffer %d of %d", id, n_bufs);
+    if (bufs[heads->params_buf[0]].cs < 109 || bufs[heads->params_buf[1]].cs < 109 || bufs[heads->prior_buf[0]].cs < 106 ||
+        bufs[heads->prior_buf[1]].cs < 106)
+      return fail(c, ACRMI_EINVAL, "head layout: params/prior buffers are too narrow");
+    for (int k = 0; k < 6; ++k)
+      if (bufs[hb[k]].h != 64 || bufs[hb[k]].w != 64) return fail(c, ACRMI_EINVAL, "head layout: head maps must be 64x64");
+  }
+  for (int i = 0; i < n_ops; ++i) {
+    const acrmi_op& op = ops[i];
+    const int ids[4] = {op.in_buf, op.out_buf, op.res_buf, op.aux_buf};
+    for (int id : ids)
+      if (id >= n_bufs || id < -1) return fail(c, ACRMI_EINVAL, "op %d references buffer %d of %d", i, id, n_bufs);
+    if (op.mode < ACRMI_MODE_BOTH || op.mode > ACRMI_MODE_POINT) return fail(c, ACRMI_EINVAL, "op %d: bad mode", i);
+    bool need_in = false, need_out = true;
+    switch (op.kind) {
+      case ACRMI_OP_U8NORM: case ACRMI_OP_POW11: case ACRMI_OP_COORDFILL: break;
+      case ACRMI_OP_CONV: case ACRMI_OP_BILINEAR2X: case ACRMI_OP_ATTPOOL: case ACRMI_OP_PAREBIAS: case ACRMI_OP_POINTHEADS:
+        need_in = true;
+        break;
+      case ACRMI_OP_FUSESUM: break;
+      default: return fail(c, ACRMI_EINVAL, "op %d: unknown kind %d", i, op.kind);
+    }
+    if ((need_in && !buf_ok(op.in_buf)) || (need_out && !buf_ok(op.out_buf)))
+      return fail(c, ACRMI_EINVAL, "op %d (kind %d): missing input/output buffer", i, op.kind);
+    if (op.in_coff < 0 || op.out_coff < 0 || op.res_coff < 0) return fail(c, ACRMI_EINVAL, "op %d: negative channel offset", i);
+    if (op.kind == ACRMI_OP_CONV) {
+      if (op.in_coff % 4 || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2 || op.cin <= 0 || op.cout <= 0 ||
+          op.groups <= 0 || (op.ksize == 1 && op.stride != 1))
+        return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
+      const int algo = op.flags & 3;
+      if (algo == 3 || (algo != 0 && !(op.ksize == 3 && op.stride == 1)))
+        return fail(c, ACRMI_EINVAL, "op %d: algo %d needs a 3x3 stride-1 convolution", i, algo);
+      if (op.in_coff + op.groups * op.cin > bufs[op.in_buf].cs || op.out_coff + op.groups * op.cout > bufs[op.out_buf].cs ||
+          (op.res_buf >= 0 && op.res_coff + op.groups * op.cout > bufs[op.res_buf].cs) || (op.groups > 1 && op.cin % 4))
+        return fail(c, ACRMI_EINVAL, "op %d: channel slice outside its buffer's channel stride", i);
+      const int pad = op.ksize / 2;
+      const int ho = (bufs[op.in_buf].h + 2 * pad - op.ksize) / op.stride + 1, wo = (bufs[op.in_buf].w + 2 * pad - op.ksize) / op.stride + 1;
+      if (ho != bufs[op.out_buf].h || wo != bufs[op.out_buf].w ||
+          (op.res_buf >= 0 && (bufs[op.res_buf].h != ho || bufs[op.res_buf].w != wo)))
+        return fail(c, ACRMI_EINVAL, "op %d: output/residual buffer geometry does not match the convolution", i);
+      const long long n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
+      const long long taps = algo == 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize);
+      const long long wn = (long long)op.groups * taps * ((op.cin + 7) / 8) * n_tiles * 256;
+      if (!w_ok(op.w_off, wn)) return fail(c, ACRMI_EINVAL, "op %d: packed weights outside the blob", i);
+      if (op.bias_per_frame) {
+        if (!buf_ok(op.aux_buf) || bufs[op.aux_buf].cs < op.groups * op.cout)
+          return fail(c, ACRMI_EINVAL, "op %d: per-frame bias buffer missing or too narrow", i);
+      } else if (!w_ok(op.b_off, (long long)op.groups * n_tiles * 32)) {
+        return fail(c, ACRMI_EINVAL, "op %d: bias outside the blob", i);
+      }
+    }
+    if (op.kind == ACRMI_OP_FUSESUM) {
+      if (op.nterms < 1 || op.nterms > 4 || op.cout <= 0 || op.cout % 4 || op.out_coff + op.cout > bufs[op.out_buf].cs)
+        return fail(c, ACRMI_EINVAL, "op %d: bad fuse-sum geometry", i);
+      for (int t = 0; t < op.nterms; ++t) {
+        if (!buf_ok(op.term_buf[t]) || op.term_coff[t] < 0 || op.term_shift[t] < 0 || op.term_shift[t] > 3 ||
+            op.term_coff[t] + op.cout > bufs[op.term_buf[t]].cs ||
+            (bufs[op.term_buf[t]].h << op.term_shift[t]) != bufs[op.out_buf].h ||
+            (bufs[op.term_buf[t]].w << op.term_shift[t]) != bufs[op.out_buf].w)
+          return fail(c, ACRMI_EINVAL, "op %d: fuse-sum term %d does not fit the output", i, t);
+      }
+    }
+    if (op.kind == ACRMI_OP_BILINEAR2X &&
+        (op.cin <= 0 || op.cin % 4 || op.in_coff % 4 || op.out_coff % 4 || op.in_coff + op.cin > bufs[op.in_buf].cs ||
+         op.out_coff + op.cin > bufs[op.out_buf].cs || bufs[op.out_buf].h != 2 * bufs[op.in_buf].h ||
+         bufs[op.out_buf].w != 2 * bufs[op.in_buf].w))
+      return fail(c, ACRMI_EINVAL, "op %d: bad bilinear geometry", i);
+    if ((op.kind == ACRMI_OP_POW11 && op.out_coff >= bufs[op.out_buf].cs) ||
+        (op.kind == ACRMI_OP_COORDFILL && op.out_coff + 2 > bufs[op.out_buf].cs))
+      return fail(c, ACRMI_EINVAL, "op %d: channel outside the buffer", i);
+    if (op.kind == ACRMI_OP_ATTPOOL) {
+      if (!buf_ok(op.res_buf) || (op.cin != 32 && op.cin != 64 && op.cin != 256 && op.cin != 320) ||
+          op.res_coff + op.cin > bufs[op.res_buf].cs || bufs[op.in_buf].cs < 33 || bufs[op.in_buf].h != 2 * bufs[op.res_buf].h ||
+          bufs[op.in_buf].w != 2 * bufs[op.res_buf].w || (long long)bufs[op.out_buf].h * bufs[op.out_buf].w * bufs[op.out_buf].cs < 32LL * op.cin)
+        return fail(c, ACRMI_EINVAL, "op %d: bad attention-pool geometry", i);
+    }
+    if (op.kind == ACRMI_OP_PAREBIAS) {
+      const long long shape_n = (op.cin == 320 ? 64 : 256) * 16;
+      if ((op.cin != 256 && op.cin != 320) || (op.flags != 0 && op.flags != 16) || bufs[op.out_buf].cs < 109 || bufs[op.out_buf].cs > 256 ||
+          (long long)bufs[op.in_buf].h * bufs[op.in_buf].w * bufs[op.in_buf].cs < 32LL * op.cin || !w_ok(op.w_off, 6 * 256 * 16) ||
+          !w_ok(op.w_off2, 10 * shape_n) || !w_ok(op.b_off2, 10) || !w_ok(op.w_off3, 109 * 106) || !w_ok(op.b_off, 109))
+        return fail(c, ACRMI_EINVAL, "op %d: bad pare-bias geometry or weights", i);
+    }
+    if (op.kind == ACRMI_OP_POINTHEADS) {
+      const bool ok = buf_ok(op.res_buf) && buf_ok(op.aux_buf) &&
+                      bufs[op.in_buf].h == 128 && bufs[op.in_buf].w == 128 && bufs[op.in_buf].cs == 36 &&
+                      bufs[op.res_buf].h == 64 && bufs[op.out_buf].h == 64 && bufs[op.res_buf].cs >= 109 &&
+                      bufs[op.out_buf].cs >= 109 && bufs[op.aux_buf].cs >= 109 && op.mode == ACRMI_MODE_POINT &&
+                      w_ok(op.w_off, 3LL * TP_TOWER_FLOATS) && w_ok(op.w_off2, 109LL * TP_EXIT_N);
+      if (!ok) return fail(c, ACRMI_EINVAL, "op %d: unsupported point-heads geometry", i);
+    }
+  }
   free_program(c);
   c->bufs.assign(bufs, bufs + n_bufs);
   c->ops.assign(ops, ops + n_ops);
@@ -339,27 +484,10 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   c->buf_ptr.assign(n_bufs, nullptr);
   for (int i = 0; i < n_bufs; ++i) {
     const auto& d = bufs[i];
-    if (d.h <= 0 || d.w <= 0 || d.cs <= 0 || d.cs % 4) return fail(c, ACRMI_EINVAL, "buffer %d: bad geometry", i);
     const size_t bytes = (size_t)max_batch * d.h * d.w * d.cs * sizeof(float);
     hipError_t e = hipMalloc(&c->buf_ptr[i], bytes);
     if (e != hipSuccess) return fail(c, ACRMI_ENOMEM, "hipMalloc(%zu) for buffer %d: %s", bytes, i, hipGetErrorString(e));
     HIPCHK(c, hipMemset(c->buf_ptr[i], 0, bytes));
-  }
-  for (int i = 0; i < n_ops; ++i) {
-    const acrmi_op& op = ops[i];
-    const int ids[4] = {op.in_buf, op.out_buf, op.res_buf, op.aux_buf};
-    for (int id : ids)
-      if (id >= n_bufs) return fail(c, ACRMI_EINVAL, "op %d references buffer %d of %d", i, id, n_bufs);
-    if (op.kind == ACRMI_OP_CONV && (op.in_coff % 4 || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2))
-      return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
-    if (op.kind == ACRMI_OP_POINTHEADS) {
-      const bool ok = op.in_buf >= 0 && op.res_buf >= 0 && op.out_buf >= 0 && op.aux_buf >= 0 &&
-                      bufs[op.in_buf].h == 128 && bufs[op.in_buf].w == 128 && bufs[op.in_buf].cs == 36 &&
-                      bufs[op.res_buf].h == 64 && bufs[op.out_buf].h == 64 && bufs[op.res_buf].cs >= 109 &&
-                      bufs[op.out_buf].cs >= 109 && bufs[op.aux_buf].cs >= 109 && op.mode == ACRMI_MODE_POINT;
-      if (!ok) return fail(c, ACRMI_EINVAL, "op %d: unsupported point-heads geometry", i);
-    }
-    if (op.mode < ACRMI_MODE_BOTH || op.mode > ACRMI_MODE_POINT) return fail(c, ACRMI_EINVAL, "op %d: bad mode", i);
   }
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
@@ -381,17 +509,25 @@ int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float
                     const float* J_regressor, const float* weights, const float* hands_mean) {
   if (!c || side < 0 || side > 1 || !v_template || !shapedirs || !posedirs || !J_regressor || !weights || !hands_mean)
     return fail(c, ACRMI_EINVAL, "acrmi_load_mano: bad arguments");
-  HIPCHK(c, hipSetDevice(c->device));
+  ON_DEVICE(c);
+  // a reload replaces the side's tables: nothing of an earlier launch may still be reading the old ones
+  HIPCHK(c, hipDeviceSynchronize());
+  for (float*& p : c->mano_allocs[side]) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  c->have_mano[side] = false;
   constexpr int NV3 = 2334;
   std::vector<float> sd_t((size_t)10 * NV3), pd_t((size_t)135 * NV3);
   for (int i = 0; i < NV3; ++i) {
     for (int k = 0; k < 10; ++k) sd_t[(size_t)k * NV3 + i] = shapedirs[(size_t)i * 10 + k];
     for (int k = 0; k < 135; ++k) pd_t[(size_t)k * NV3 + i] = posedirs[(size_t)i * 135 + k];
   }
+  int n_up = 0;
   auto up = [&](const float* h, size_t n, const float** dst) -> int {
     float* d = nullptr;
     HIPCHK(c, hipMalloc(&d, n * sizeof(float)));
-    c->mano_allocs.push_back(d);
+    c->mano_allocs[side][n_up++] = d;
     HIPCHK(c, hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
     *dst = d;
     return ACRMI_OK;
@@ -442,6 +578,7 @@ static int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bo
   if (!c || !img) return fail(c, ACRMI_EINVAL, "acrmi_backbone_heads: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_heads: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  ON_DEVICE(c);
   static const bool dbg_sync = getenv("ACRMI_DEBUG_SYNC") != nullptr;   // attribute a fault/hang to an op
   if (c->sched[point ? 1 : 0][B > AUTO_SMALL_BATCH ? 1 : 0].n_lanes > 1 && !dbg_sync)
     return run_program_lanes(c, img, B, (hipStream_t)stream, point);
@@ -465,6 +602,7 @@ int acrmi_point_heads(acrmi_ctx* c, int B, void* stream) {
   if (!c) return fail(c, ACRMI_EINVAL, "acrmi_point_heads: ctx is NULL");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_point_heads: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  ON_DEVICE(c);
   int n = 0;
   for (const acrmi_op& op : c->ops)
     if (op.kind == ACRMI_OP_POINTHEADS) {
@@ -494,7 +632,63 @@ int acrmi_set_option(acrmi_ctx* c, int option, int value) {
       for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
     return ACRMI_OK;
   }
+  if (option == ACRMI_OPT_CENTER_IDX) {
+    if (value < -1 || value > 20) return fail(c, ACRMI_EINVAL, "acrmi_set_option: center_idx %d outside -1..20", value);
+    c->center_idx = value;
+    return ACRMI_OK;
+  }
+  if (option == ACRMI_OPT_TEMPORAL) {
+    c->temporal = value != 0;
+    return ACRMI_OK;
+  }
   return fail(c, ACRMI_EINVAL, "acrmi_set_option: unknown option %d", option);
+}
+
+int acrmi_set_option_f(acrmi_ctx* c, int option, float value) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_set_option_f: ctx is NULL");
+  if (option == ACRMI_OPT_CONF_THRESH) {
+    if (!(value == value)) return fail(c, ACRMI_EINVAL, "acrmi_set_option_f: threshold is NaN");
+    c->conf_thresh = value;
+    return ACRMI_OK;
+  }
+  if (option == ACRMI_OPT_SMOOTH_COEFF) {
+    if (!(value > 0.f)) return fail(c, ACRMI_EINVAL, "acrmi_set_option_f: smooth_coeff must be > 0");
+    c->smooth_coeff = value;
+    return ACRMI_OK;
+  }
+  return fail(c, ACRMI_EINVAL, "acrmi_set_option_f: unknown option %d", option);
+}
+
+// ---- temporal smoothing (acr/main.py:69-83) -------------------------------------------------------------
+constexpr size_t SMOOTH_STATE_BYTES = 2 * 3 * 64 * sizeof(float) + 2 * sizeof(int);
+
+int acrmi_smooth_reset(acrmi_ctx* c, void* stream) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_smooth_reset: ctx is NULL");
+  ON_DEVICE(c);
+  if (!c->smooth_state) HIPCHK(c, hipMalloc(&c->smooth_state, SMOOTH_STATE_BYTES));
+  HIPCHK(c, hipMemsetAsync(c->smooth_state, 0, SMOOTH_STATE_BYTES, (hipStream_t)stream));
+  return ACRMI_OK;
+}
+
+int acrmi_smooth(acrmi_ctx* c, float* slots, int B, void* stream) {
+  if (!c || !slots || B <= 0) return fail(c, ACRMI_EINVAL, "acrmi_smooth: bad arguments");
+  ON_DEVICE(c);
+  if (!c->smooth_state) {
+    int r = acrmi_smooth_reset(c, stream);
+    if (r) return r;
+  }
+  SmoothArgs a{};
+  a.slots = slots; a.B = B;
+  a.state = c->smooth_state;
+  a.init = reinterpret_cast<int*>(c->smooth_state + 2 * 3 * 64);
+  // create_OneEuroFilter (acr/utils.py:1472-1473): poses / global_orient (smooth_coeff, 0.7), betas (0.6, 0.7);
+  // dcutoff 1.0, freq 30.  The derivative filter's alpha is a python double rounded once when it meets the tensor.
+  a.mincutoff = c->smooth_coeff; a.mincutoff_betas = 0.6f; a.beta = 0.7f; a.freq = 30.f;
+  const double te = 1.0 / 30.0, tau = 1.0 / (2 * M_PI * 1.0), alpha_d = 1.0 / (1.0 + tau / te);
+  a.alpha_d = (float)alpha_d; a.one_minus_alpha_d = (float)(1.0 - alpha_d);
+  a.two_pi = (float)(2 * M_PI); a.te = (float)te;
+  HIPCHK(c, launch_smooth(a, (hipStream_t)stream));
+  return ACRMI_OK;
 }
 
 int acrmi_profile_ops(acrmi_ctx* c, const uint8_t* img, int B, float* ms_out, int n_ms, void* stream) {
@@ -502,23 +696,29 @@ int acrmi_profile_ops(acrmi_ctx* c, const uint8_t* img, int B, float* ms_out, in
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "no program");
   const int n = (int)c->ops.size();
   if (n_ms < n) return fail(c, ACRMI_EINVAL, "ms_out too small (%d < %d)", n_ms, n);
+  ON_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   const bool point = c->point_heads;
   int r = run_program(c, img, B, stream, point);
   if (r) return r;
-  std::vector<hipEvent_t> ev(n + 1);
-  for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
-  HIPCHK(c, hipEventRecord(ev[0], s));
-  for (int i = 0; i < n; ++i) {
-    if (op_active(c->ops[i], point)) {
-      r = run_op(c, c->ops[i], img, B, s);
-      if (r) return r;
-    }
-    HIPCHK(c, hipEventRecord(ev[i + 1], s));
+  std::vector<hipEvent_t> ev(n + 1, nullptr);
+  auto cleanup = [&]() {
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  };
+  hipError_t he = hipSuccess;
+  for (auto& e : ev)
+    if ((he = hipEventCreate(&e)) != hipSuccess) break;
+  if (he == hipSuccess) he = hipEventRecord(ev[0], s);
+  for (int i = 0; i < n && he == hipSuccess && r == ACRMI_OK; ++i) {
+    if (op_active(c->ops[i], point)) r = run_op(c, c->ops[i], img, B, s);
+    if (r == ACRMI_OK) he = hipEventRecord(ev[i + 1], s);
   }
-  HIPCHK(c, hipStreamSynchronize(s));
-  for (int i = 0; i < n; ++i) HIPCHK(c, hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (he == hipSuccess && r == ACRMI_OK) he = hipStreamSynchronize(s);
+  for (int i = 0; i < n && he == hipSuccess && r == ACRMI_OK; ++i) he = hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+  cleanup();
+  if (r) return r;
+  if (he != hipSuccess) return fail(c, ACRMI_EHIP, "acrmi_profile_ops: %s", hipGetErrorString(he));
   return n;
 }
 
@@ -532,14 +732,15 @@ void* acrmi_buffer_ptr(acrmi_ctx* c, int buf, int* h, int* w, int* cs) {
 
 int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs, const float* l_params,
                       const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
-                      int B, float* slots, void* stream) {
-  if (!l_center || !r_center || !l_params || !r_params || !l_prior || !r_prior || !slots || B <= 0)
+                      int B, float conf_thresh, float* slots, void* stream) {
+  if (!l_center || !r_center || !l_params || !r_params || !l_prior || !r_prior || !slots || B <= 0 || params_cs < 109 ||
+      prior_cs < 106 || center_cs < 1 || !(conf_thresh == conf_thresh))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_decode_maps: bad arguments");
   DecodeArgs d{};
   d.center[0] = l_center; d.center[1] = r_center; d.center_cs = center_cs;
   d.params[0] = l_params; d.params[1] = r_params; d.params_cs = params_cs;
   d.prior[0] = l_prior; d.prior[1] = r_prior; d.prior_cs = prior_cs;
-  d.B = B; d.slots = slots;
+  d.B = B; d.slots = slots; d.thresh = conf_thresh;
   hipError_t e = launch_decode(d, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "decode launch: %s", hipGetErrorString(e));
   return ACRMI_OK;
@@ -549,11 +750,12 @@ int acrmi_decode(acrmi_ctx* c, int B, float* slots, void* stream) {
   if (!c || !slots) return fail(c, ACRMI_EINVAL, "acrmi_decode: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_decode: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  ON_DEVICE(c);
   const acrmi_head_layout& h = c->heads;
   int r = acrmi_decode_maps(c->buf_ptr[h.center_buf[0]], c->buf_ptr[h.center_buf[1]], c->bufs[h.center_buf[0]].cs,
                             c->buf_ptr[h.params_buf[0]], c->buf_ptr[h.params_buf[1]], c->bufs[h.params_buf[0]].cs,
                             c->buf_ptr[h.prior_buf[0]], c->buf_ptr[h.prior_buf[1]], c->bufs[h.prior_buf[0]].cs, B,
-                            slots, stream);
+                            c->conf_thresh, slots, stream);
   if (r) c->err = g_err;
   return r;
 }
@@ -567,6 +769,7 @@ int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* b
   if (H < 0 || !poses || !betas || !verts || !joints || center_idx >= 21)
     return fail(c, ACRMI_EINVAL, "acrmi_mano: bad arguments");
   if (!c->have_mano[0] && !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_mano: MANO tables not loaded");
+  ON_DEVICE(c);
   ManoArgs m{};
   // a context may hold one side only (a lone ManoLayer); rows must then all be of that side
   m.t[0] = c->have_mano[0] ? c->mano[0] : c->mano[1];
@@ -585,11 +788,12 @@ static int forward_tail(acrmi_ctx* c, int B, const float* offsets, float* slots,
                         float* verts_camed, float* pj2d, float* pj2d_org, hipStream_t stream) {
   int r = acrmi_decode(c, B, slots, stream);
   if (r) return r;
+  if (c->temporal && (r = acrmi_smooth(c, slots, B, stream))) return r;   // acr/main.py:69-83, before MANO
   ManoArgs m{};
   m.t[0] = c->mano[0]; m.t[1] = c->mano[1];
   m.poses = slots + ACRMI_SLOT_POSES; m.pose_stride = ACRMI_SLOT;
   m.betas = slots + ACRMI_SLOT_BETAS; m.beta_stride = ACRMI_SLOT;
-  m.side = nullptr; m.H = 2 * B; m.center_idx = 9;
+  m.side = nullptr; m.H = 2 * B; m.center_idx = c->center_idx;
   m.verts = verts; m.joints = joints; m.center = nullptr;
   const bool proj = verts_camed || pj2d || pj2d_org;
   m.cam = proj ? slots + ACRMI_SLOT_CAM : nullptr; m.cam_stride = ACRMI_SLOT;
@@ -603,6 +807,7 @@ int acrmi_forward(acrmi_ctx* c, const uint8_t* img, int B, const float* offsets,
                   float* joints, float* verts_camed, float* pj2d, float* pj2d_org, void* stream) {
   if (!c || !slots || !verts || !joints) return fail(c, ACRMI_EINVAL, "acrmi_forward: bad arguments");
   if (!c->have_mano[0] || !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_forward: MANO tables not loaded");
+  ON_DEVICE(c);
   int r = run_program(c, img, B, stream, c->point_heads);
   if (r) return r;
   return forward_tail(c, B, offsets, slots, verts, joints, verts_camed, pj2d, pj2d_org, (hipStream_t)stream);
@@ -701,6 +906,99 @@ int acrmi_cam_trans(const float* joints_dev, const float* pj2d_dev, int n, float
     return fail(nullptr, ACRMI_EINVAL, "acrmi_cam_trans: bad arguments");
   hipError_t e = launch_cam_trans(joints_dev, pj2d_dev, n, focal_length, img_size, trans_dev, (hipStream_t)stream);
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "cam_trans: %s", hipGetErrorString(e));
+}
+
+// ---- multi-GPU: RCCL all-gather of the result slots -----------------------------------
+// libacrmi.so has no link-time dependency on RCCL: the library is resolved at the first call - the copy the process
+// already holds (PyTorch ships its own librccl.so) or the ROCm one.
+namespace {
+struct RcclId { char internal[128]; };   // ncclUniqueId (rccl.h:43)
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool tried = false;
+};
+Rccl g_rccl;
+constexpr int RCCL_FLOAT32 = 7;          // ncclFloat32 (rccl.h:466)
+
+bool rccl_load() {
+  if (g_rccl.tried) return g_rccl.lib != nullptr;
+  g_rccl.tried = true;
+  const char* env = getenv("ACRMI_RCCL_LIB");
+  const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)      // already mapped into the process?
+    if (n && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  for (const char* n : names) {
+    if (h) break;
+    if (n) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!h) return false;
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
+    return false;
+  g_rccl.lib = h;
+  return true;
+}
+const char* rccl_err(int r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
+}  // namespace
+
+static void comm_destroy(acrmi_ctx* c) {
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->comm_ranks = 0;
+}
+
+int acrmi_comm_unique_id(void* id128) {
+  if (!id128) return fail(nullptr, ACRMI_EINVAL, "acrmi_comm_unique_id: id is NULL");
+  if (!rccl_load()) return fail(nullptr, ACRMI_ESTATE, "RCCL (librccl.so) could not be loaded: %s", dlerror());
+  RcclId id;
+  const int r = g_rccl.GetUniqueId(&id);
+  if (r) return fail(nullptr, ACRMI_EHIP, "ncclGetUniqueId: %s", rccl_err(r));
+  memcpy(id128, &id, sizeof id);
+  return ACRMI_OK;
+}
+
+int acrmi_comm_init(acrmi_ctx* c, int n_ranks, int rank, const void* id128) {
+  if (!c || !id128 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(c, ACRMI_EINVAL, "acrmi_comm_init: bad arguments");
+  if (!rccl_load()) return fail(c, ACRMI_ESTATE, "RCCL (librccl.so) could not be loaded: %s", dlerror());
+  ON_DEVICE(c);
+  comm_destroy(c);
+  RcclId id;
+  memcpy(&id, id128, sizeof id);
+  const int r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+  if (r) {
+    c->comm = nullptr;
+    return fail(c, ACRMI_EHIP, "ncclCommInitRank(%d of %d): %s", rank, n_ranks, rccl_err(r));
+  }
+  c->comm_ranks = n_ranks;
+  return ACRMI_OK;
+}
+
+int acrmi_comm_destroy(acrmi_ctx* c) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_comm_destroy: ctx is NULL");
+  ON_DEVICE(c);
+  comm_destroy(c);
+  return ACRMI_OK;
+}
+
+int acrmi_allgather(acrmi_ctx* c, void* nccl_comm, const float* send_dev, float* recv_dev, size_t n_floats, void* stream) {
+  if (!c || !send_dev || !recv_dev || n_floats == 0) return fail(c, ACRMI_EINVAL, "acrmi_allgather: bad arguments");
+  void* comm = nccl_comm ? nccl_comm : c->comm;
+  if (!comm) return fail(c, ACRMI_ESTATE, "acrmi_allgather: no communicator (acrmi_comm_init, or pass an ncclComm_t)");
+  if (!rccl_load()) return fail(c, ACRMI_ESTATE, "RCCL (librccl.so) could not be loaded");
+  ON_DEVICE(c);
+  const int r = g_rccl.AllGather(send_dev, recv_dev, n_floats, RCCL_FLOAT32, comm, (hipStream_t)stream);
+  if (r) return fail(c, ACRMI_EHIP, "ncclAllGather: %s", rccl_err(r));
+  return ACRMI_OK;
 }
 
 int acrmi_tune(int key, int value) {

@@ -38,7 +38,9 @@ static long long* g_dbg = nullptr;
 void conv_set_debug(long long* dbg) { g_dbg = dbg; }
 static int g_phase_delay = 0;
 void conv_set_phase_delay(int cycles) { g_phase_delay = cycles; }
-static int g_num_cus = 0;
+// per-device state: a process may hold contexts on several GPUs (acr.main.ACR(device=...)); kernel attributes
+// (dynamic LDS size) and the CU count belong to a device, not to the process
+static int g_num_cus_dev[MAX_DEVICES] = {};
 // Cache policy of the residual loads (aux operand of raw.buffer.load: 0 default, 2 slc = streaming): a residual
 // element is read exactly once per launch.  Measured (batch 64): the HBM-bound 64->256 1x1 + residual layer 0.611 ->
 // 0.583 ms with slc; the Winograd layers do not care (0.158 vs 0.161 ms), they keep the default.
@@ -556,16 +558,26 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_win
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-static hipError_t ensure_device_info() {
-  if (g_num_cus) return hipSuccess;
+static int current_device() {
   int dev = 0;
-  hipDeviceProp_t prop;
-  hipError_t e = hipGetDevice(&dev);
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  return dev;
+}
+static hipError_t ensure_device_info() {
+  const int dev = current_device();
+  if (g_num_cus_dev[dev]) return hipSuccess;
+  int n = 0;
+  hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
   if (e != hipSuccess) return e;
-  e = hipGetDeviceProperties(&prop, dev);
-  if (e != hipSuccess) return e;
-  g_num_cus = prop.multiProcessorCount;
+  g_num_cus_dev[dev] = n;
   return hipSuccess;
+}
+// true the first time `flags` (a per-kernel-instantiation array) is asked about the current device
+bool first_use_on_device(unsigned char* flags) {
+  const int dev = current_device();
+  if (flags[dev]) return false;
+  flags[dev] = 1;
+  return true;
 }
 
 // One persistent workgroup per CU.  (Two per CU were measured: the 384-thread workgroups do not become
@@ -573,7 +585,7 @@ static hipError_t ensure_device_info() {
 // after the first - so k = 2 only adds a second prologue/tail; PMC: profiles/r01_pmc_wino_b2.txt.)
 static long pick_grid(long total, size_t lds_bytes) {
   (void)lds_bytes;
-  const long grid = g_num_cus;
+  const long grid = g_num_cus_dev[current_device()];
   return grid > total ? total : grid;
 }
 
@@ -584,8 +596,8 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "patch and residual buffers must fit the 160 KiB LDS");
   constexpr int NTHREADS = (WAVES_M * WAVES_N + NLW) * 64;
   auto kern = conv_wino_kernel<TH, TW, WAVES_M, WAVES_N, CK, NLW, ABL, MINW>;
-  static bool init = false;
-  if (!init) {
+  static unsigned char init[MAX_DEVICES] = {};
+  if (first_use_on_device(init)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -598,7 +610,6 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
       fprintf(stderr, "[acrmi] conv_wino<%d,%d,%d,%d,%d,%d>: threads %d lds %zu regs %d occupancy(API) %d blocks/CU\n", TH, TW,
               WAVES_M, WAVES_N, CK, NLW, NTHREADS, lds, fa.numRegs, occ);
     }
-    init = true;
   }
   ConvWork wk;
   wk.tiles_x = (a.Wo + TW - 1) / TW;
@@ -608,7 +619,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
   wk.total = wk.n_tiles_total * wk.nblk * a.groups;
   long grid = pick_grid(wk.total, lds);
   if (MINW >= 3) {   // register budget allows two co-resident workgroups per CU
-    const long g2 = 2L * g_num_cus;
+    const long g2 = 2L * g_num_cus_dev[current_device()];
     grid = g2 > wk.total ? wk.total : g2;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, a, wk);

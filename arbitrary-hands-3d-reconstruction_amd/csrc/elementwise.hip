@@ -131,44 +131,60 @@ hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, h
 namespace acrmi {
 
 // ------------------------------------------------------------------------------------------------
-// Pre-processing (acr/utils.py:1315-1337): BGR uint8 frame [H,W,3] -> white-padded square
-// (imgaug Pad semantics: extra pixel goes to bottom/right) -> bicubic resize (a = -0.75, half-pixel centres,
-// replicate border - the OpenCV INTER_CUBIC / torch bicubic kernel) to 512x512 RGB uint8.  One thread per
-// output pixel; the 1080p source (6.2 MB/frame) is read once through L2.
+// Pre-processing (acr/utils.py:1315-1337): BGR uint8 frame [H,W,3] -> white-padded square (imgaug
+// 0.4.0 Pad: the extra pixel goes to bottom/right) -> cv2.resize(..., (512,512), INTER_CUBIC) -> RGB uint8.
+// The resize is OpenCV's uint8 path restated from its published source (modules/imgproc/src/resize.cpp), bit for bit:
+//   fx = (float)((dx + 0.5) * scale - 0.5) with scale in double, sx = floor(fx), fx -= sx;
+//   coefficients interpolateCubic(fx) with A = -0.75 in float, stored as short = round-half-even(c * 2048)
+//   (INTER_RESIZE_COEF_BITS = 11); horizontal pass in int32 over 4 border-clamped columns; vertical pass in int32
+//   over 4 border-clamped rows; dst = saturate((v + 2^21) >> 22)   (FixedPtCast<int, uchar, 22>).
+// oracle/preprocess.py is the CPU statement of the same algorithm; tests require equality.
+// One thread per output pixel; the 1080p source (6.2 MB/frame) is read once through L2.
 // ------------------------------------------------------------------------------------------------
-__device__ inline float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
-__device__ inline float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ inline void cv_cubic_taps(int d, double scale, int& s0, int (&c)[4]) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  const float fl = floorf(f);
+  s0 = (int)fl;
+  f -= fl;
+  const float A = -0.75f;
+  float k[4];
+  k[0] = ((A * (f + 1.f) - 5.f * A) * (f + 1.f) + 8.f * A) * (f + 1.f) - 4.f * A;
+  k[1] = ((A + 2.f) * f - (A + 3.f)) * f * f + 1.f;
+  k[2] = ((A + 2.f) * (1.f - f) - (A + 3.f)) * (1.f - f) * (1.f - f) + 1.f;
+  k[3] = 1.f - k[0] - k[1] - k[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int v = (int)rintf(k[i] * 2048.f);            // saturate_cast<short>(float): cvRound, then clamp
+    c[i] = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+  }
+}
 
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ bgr, int n, int H, int W, int S,
                                                          int pad_top, int pad_left, int out_size,
                                                          uint8_t* __restrict__ out) {
   const long total = (long)n * out_size * out_size;
-  const float scale = (float)S / (float)out_size;
-  const float A = -0.75f;
+  const double scale = (double)S / (double)out_size;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ox = i % out_size;
     const int oy = (i / out_size) % out_size;
     const int f = i / ((long)out_size * out_size);
-    const float fy = scale * (oy + 0.5f) - 0.5f, fx = scale * (ox + 0.5f) - 0.5f;
-    const float fly = floorf(fy), flx = floorf(fx);
-    const float ty = fy - fly, tx = fx - flx;
-    const int sy = (int)fly, sx = (int)flx;
-    const float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
-    const float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
-    float acc[3] = {0.f, 0.f, 0.f};
+    int sy, sx, cy[4], cx[4];
+    cv_cubic_taps(oy, scale, sy, cy);
+    cv_cubic_taps(ox, scale, sx, cx);
+    int acc[3] = {0, 0, 0};
     const uint8_t* src = bgr + (size_t)f * H * W * 3;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       int yy = sy - 1 + a;
-      yy = yy < 0 ? 0 : (yy >= S ? S - 1 : yy);      // replicate border of the padded square
+      yy = yy < 0 ? 0 : (yy >= S ? S - 1 : yy);      // border rows / columns of the padded square are clamped
       const int iy = yy - pad_top;
-      float row[3] = {0.f, 0.f, 0.f};
+      int row[3] = {0, 0, 0};
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         int xx = sx - 1 + b;
         xx = xx < 0 ? 0 : (xx >= S ? S - 1 : xx);
         const int ix = xx - pad_left;
-        float v0 = 255.f, v1 = 255.f, v2 = 255.f;   // white padding (acr/utils.py:1305-1310)
+        int v0 = 255, v1 = 255, v2 = 255;           // white padding (acr/utils.py:1303-1308)
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
           const uint8_t* p = src + ((size_t)iy * W + ix) * 3;
           v0 = p[2]; v1 = p[1]; v2 = p[0];          // BGR -> RGB (acr/utils.py:1318)
@@ -180,9 +196,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     uint8_t* o = out + (size_t)i * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float r = rintf(acc[c]);
-      r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
-      o[c] = (uint8_t)r;
+      const int r = (acc[c] + (1 << 21)) >> 22;
+      o[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
     }
   }
 }

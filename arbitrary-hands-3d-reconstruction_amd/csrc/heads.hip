@@ -196,20 +196,12 @@ hipError_t launch_parebias(const PareArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // Center decode, one workgroup per frame (acr/result_parser.py:85-190,218-249; acr/utils.py:334-382,773-906)
 // ------------------------------------------------------------------------------------------------
-__device__ inline void rot6d_to_aa(const float* x6, float* aa) {
-  // x.view(3,2): b1 = (x0,x2,x4), a2 = (x1,x3,x5)  (acr/utils.py:362-376)
-  float b1[3] = {x6[0], x6[2], x6[4]}, a2[3] = {x6[1], x6[3], x6[5]};
-  float n1 = fmaxf(sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]), 1e-6f);
-  b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
-  const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
-  float b2[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
-  float n2 = fmaxf(sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]), 1e-6f);
-  b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
-  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
-  // R = [b1 b2 b3] as columns; t = R^T, so t[i][j] = R[j][i]: rows of t are b1, b2, b3
-  const float t00 = b1[0], t01 = b1[1], t02 = b1[2];
-  const float t10 = b2[0], t11 = b2[1], t12 = b2[2];
-  const float t20 = b3[0], t21 = b3[1], t22 = b3[2];
+// rotation matrix -> axis-angle (acr/utils.py:334-360 -> :826-906 -> :773-823).  t = the TRANSPOSED matrix, row-major
+// (the reference transposes first, :857).
+__device__ inline void rotmat_t_to_aa(const float* t, float* aa) {
+  const float t00 = t[0], t01 = t[1], t02 = t[2];
+  const float t10 = t[3], t11 = t[4], t12 = t[5];
+  const float t20 = t[6], t21 = t[7], t22 = t[8];
   float q[4], tr;
   if (t22 < 1e-6f) {
     if (t00 > t11) {
@@ -228,11 +220,9 @@ __device__ inline void rot6d_to_aa(const float* x6, float* aa) {
       q[0] = tr; q[1] = t12 - t21; q[2] = t20 - t02; q[3] = t01 - t10;
     }
   }
-  const float sc = 0.5f / sqrtf(tr);
   // reference: q /= sqrt(t); q *= 0.5
   const float rs = sqrtf(tr);
   q[0] = (q[0] / rs) * 0.5f; q[1] = (q[1] / rs) * 0.5f; q[2] = (q[2] / rs) * 0.5f; q[3] = (q[3] / rs) * 0.5f;
-  (void)sc;
   const float s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
   const float sn = sqrtf(s2), cs = q[0];
   const float two_theta = 2.0f * (cs < 0.f ? atan2f(-sn, -cs) : atan2f(sn, cs));
@@ -241,6 +231,21 @@ __device__ inline void rot6d_to_aa(const float* x6, float* aa) {
     float v = q[1 + e] * k;
     aa[e] = (v != v) ? 0.f : v;   // NaN -> 0 (acr/utils.py:359)
   }
+}
+
+__device__ inline void rot6d_to_aa(const float* x6, float* aa) {
+  // x.view(3,2): b1 = (x0,x2,x4), a2 = (x1,x3,x5)  (acr/utils.py:362-376)
+  float b1[3] = {x6[0], x6[2], x6[4]}, a2[3] = {x6[1], x6[3], x6[5]};
+  float n1 = fmaxf(sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]), 1e-6f);
+  b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
+  const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  float b2[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+  float n2 = fmaxf(sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]), 1e-6f);
+  b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+  // R = [b1 b2 b3] as columns; t = R^T, so t[i][j] = R[j][i]: rows of t are b1, b2, b3
+  const float t[9] = {b1[0], b1[1], b1[2], b2[0], b2[1], b2[2], b3[0], b3[1], b3[2]};
+  rotmat_t_to_aa(t, aa);
 }
 
 // NMS + arg-max + threshold of both center maps of frame b (acr/result_parser.py:218-249) and the cross-hand prior
@@ -254,7 +259,8 @@ struct PickScratch {
   float bestv[2][4];
   int besti[2][4];
 };
-__device__ inline void pick_centers(const float* const* center, int center_cs, int b, PickScratch& sc, CenterPick& pk) {
+__device__ inline void pick_centers(const float* const* center, int center_cs, int b, float thresh, PickScratch& sc,
+                                    CenterPick& pk) {
   const int tid = threadIdx.x;
   for (int h = 0; h < 2; ++h)
     for (int i = tid; i < 4096; i += 256) sc.cmap[h][i] = center[h][((size_t)b * 4096 + i) * center_cs];
@@ -288,7 +294,7 @@ __device__ inline void pick_centers(const float* const* center, int center_cs, i
       int bi = sc.besti[h][0];
       for (int w = 1; w < 4; ++w)
         if (sc.bestv[h][w] > bv || (sc.bestv[h][w] == bv && sc.besti[h][w] < bi)) { bv = sc.bestv[h][w]; bi = sc.besti[h][w]; }
-      pk.flag[h] = bv > 0.35f;                        // strict (acr/result_parser.py:241)
+      pk.flag[h] = bv > thresh;                       // strict; centermap_conf_thresh (acr/result_parser.py:241)
       pk.flat[h] = pk.flag[h] ? bi : 0;               // placeholder samples pixel 0 (:106-120)
       pk.score[h] = bv;
     }
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
   __shared__ PickScratch sc;
   __shared__ CenterPick pk;
   __shared__ float pred[2][112];
-  pick_centers(a.center, a.center_cs, b, sc, pk);
+  pick_centers(a.center, a.center_cs, b, a.thresh, sc, pk);
   const int* s_flat = pk.flat;
   const int* s_flag = pk.flag;
   const float* s_score = pk.score;
@@ -350,6 +356,81 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Temporal smoothing between decode and MANO (acr/main.py:69-83, acr/utils.py:1466-1527): one One-Euro filter set
+// per hand type (poses[3:48], betas, and the global orientation as a 3x3 rotation matrix), applied to the frames of
+// ONE video stream in order.  State (per hand: x_raw / x_filt / dx_filt of 64 elements + an init flag) lives in the
+// context.  Element e of a hand: 0..44 finger pose, 45..54 betas, 55..63 rotation-matrix entries.
+// Arithmetic follows torch's: python scalars meet float32 tensors as float32; the first sample passes through.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void smooth_kernel(const SmoothArgs a) {
+  const int tid = threadIdx.x, h = tid >> 6, e = tid & 63;
+  __shared__ float rot[2][9];
+  float* st = a.state + h * 3 * 64;     // [x_raw | x_filt | dx_filt][64]
+  float x_raw = st[e], x_filt = st[64 + e], dx_filt = st[128 + e];
+  int init = a.init[h];
+  const float mincut = (e >= 45 && e < 55) ? a.mincutoff_betas : a.mincutoff;
+  for (int b = 0; b < a.B; ++b) {
+    float* sl = a.slots + ((size_t)b * 2 + h) * ACRMI_SLOT;
+    const bool on = sl[ACRMI_SLOT_FLAG] > 0.5f;     // block-uniform per hand (wave = hand)
+    if (on && e == 55) {      // batch_rodrigues (acr/utils.py:602-616) + quat2mat (:618-638) of the global orientation
+      const float ax = sl[ACRMI_SLOT_POSES], ay = sl[ACRMI_SLOT_POSES + 1], az = sl[ACRMI_SLOT_POSES + 2];
+      const float ex = ax + 1e-8f, ey = ay + 1e-8f, ez = az + 1e-8f;
+      const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+      const float nx = ax / angle, ny = ay / angle, nz = az / angle;
+      const float half = angle * 0.5f;
+      const float sn = sinf(half);
+      float w = cosf(half), x = sn * nx, y = sn * ny, z = sn * nz;
+      const float qn = sqrtf(w * w + x * x + y * y + z * z);
+      w /= qn; x /= qn; y /= qn; z /= qn;
+      const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+      const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+      float* R = rot[h];
+      R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;    R[2] = 2 * wy + 2 * xz;
+      R[3] = 2 * wz + 2 * xy;   R[4] = w2 - x2 + y2 - z2;  R[5] = 2 * yz - 2 * wx;
+      R[6] = 2 * xz - 2 * wy;   R[7] = 2 * wx + 2 * yz;    R[8] = w2 - x2 - y2 + z2;
+    }
+    __syncthreads();
+    if (on) {
+      const float x = e < 45 ? sl[ACRMI_SLOT_POSES + 3 + e] : (e < 55 ? sl[ACRMI_SLOT_BETAS + (e - 45)] : rot[h][e - 55]);
+      float s;
+      if (!init) {
+        s = x;
+        dx_filt = 0.f;
+      } else {
+        const float dx = (x - x_raw) * a.freq;
+        const float edx = a.alpha_d * dx + a.one_minus_alpha_d * dx_filt;
+        const float cutoff = mincut + a.beta * fabsf(edx);
+        const float tau = 1.0f / (a.two_pi * cutoff);
+        const float al = 1.0f / (1.0f + tau / a.te);
+        s = al * x + (1.0f - al) * x_filt;
+        dx_filt = edx;
+      }
+      x_raw = x;
+      x_filt = s;
+      if (e < 45) sl[ACRMI_SLOT_POSES + 3 + e] = s;
+      else if (e < 55) sl[ACRMI_SLOT_BETAS + (e - 45)] = s;
+      else rot[h][e - 55] = s;
+    }
+    __syncthreads();
+    if (on && e == 55) {      // rotation_matrix_to_angle_axis (acr/utils.py:334-360); the reference transposes first
+      const float* R = rot[h];
+      const float t[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+      float aa[3];
+      rotmat_t_to_aa(t, aa);
+      sl[ACRMI_SLOT_POSES] = aa[0]; sl[ACRMI_SLOT_POSES + 1] = aa[1]; sl[ACRMI_SLOT_POSES + 2] = aa[2];
+    }
+    if (on) init = 1;
+    __syncthreads();
+  }
+  st[e] = x_raw; st[64 + e] = x_filt; st[128 + e] = dx_filt;
+  if (e == 0) a.init[h] = init;
+}
+hipError_t launch_smooth(const SmoothArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(smooth_kernel, dim3(1), dim3(128), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Point heads.  ResultParser reads the 109-ch params map at ONE pixel per hand (its own center,
 // acr/result_parser.py:49-57,105,115) and the 106-ch prior map at ONE pixel (the other hand's center, :141-145), so
 // after the center heads have run the other six head towers (acr/model.py:71-99,288-313: 3x3 s2 entry conv, two
@@ -367,7 +448,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(256) void center_pick_kernel(const PointArgs a) {
   __shared__ PickScratch sc;
   __shared__ CenterPick pk;
-  pick_centers(a.center, a.center_cs, blockIdx.x, sc, pk);
+  pick_centers(a.center, a.center_cs, blockIdx.x, a.thresh, sc, pk);
   if (threadIdx.x == 0) {
     int* o = a.picks + blockIdx.x * 4;
     o[0] = pk.flat[0]; o[1] = pk.flat[1]; o[2] = pk.prior; o[3] = 0;
@@ -567,14 +648,13 @@ __global__ __launch_bounds__(128) void point_mix_kernel(const PointArgs a) {
 }
 
 hipError_t launch_point_heads(const PointArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned char attr_set[MAX_DEVICES] = {};
   constexpr int LDS_BYTES = TP_LDS_FLOATS * (int)sizeof(float);
   static_assert(TP_XIN >= (49 + 25 + 9 + 1 + TP_WAVES) * 64, "window buffers alias the dead x34 window");
-  if (!attr_set) {
+  if (first_use_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_point_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(center_pick_kernel, dim3(a.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(tower_point_kernel, dim3(a.B * 3), dim3(TP_WAVES * 64), LDS_BYTES, s, a);

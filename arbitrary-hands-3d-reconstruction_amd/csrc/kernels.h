@@ -25,6 +25,11 @@ struct ConvArgs {
   int phase_delay;      // tuning: cycles the second half of the grid sleeps before starting (0 = off)
 };
 
+// one-time per-DEVICE kernel setup (dynamic LDS attribute): true the first time `flags` (one static array per kernel
+// instantiation) is asked about the current device
+constexpr int MAX_DEVICES = 64;
+bool first_use_on_device(unsigned char* flags);
+
 // returns hipSuccess or the launch error; cout tiles etc. derived inside
 hipError_t launch_conv(ConvArgs a, hipStream_t s);
 const char* conv_kernel_name(const ConvArgs& a);
@@ -74,8 +79,21 @@ struct DecodeArgs {
   int center_cs, params_cs, prior_cs;
   int B;
   float* slots;
+  float thresh;          // centermap_conf_thresh (acr/result_parser.py:241), strict >
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+
+// One-Euro smoothing of the decoded (poses, betas) of one video stream, frames in order (acr/utils.py:1466-1527)
+struct SmoothArgs {
+  float* slots;          // [B,2,ACRMI_SLOT], smoothed in place where the flag is set
+  int B;
+  float* state;          // [2 hands][x_raw | x_filt | dx_filt][64]
+  int* init;             // [2]
+  float mincutoff, mincutoff_betas, beta, freq;
+  float alpha_d, one_minus_alpha_d;   // derivative filter: compute_alpha(dcutoff) in double, rounded once
+  float two_pi, te;
+};
+hipError_t launch_smooth(const SmoothArgs& a, hipStream_t s);
 
 // Point heads: the six non-center head towers evaluated only at the pixels the decode reads (heads.hip).
 // Per tower (floats): entry W [9 taps][9 cin/4][64 cout][4] + b[64]; 4 x (conv W [9][16][64][4] + b[64]);
@@ -95,6 +113,7 @@ struct PointArgs {
   float* final_; int final_cs;             // [B,64,64,cs] 109-ch params map after the mix
   int* picks;                              // [B,4] workspace: flat_l, flat_r, prior gate
   int side, B;
+  float thresh;                            // centermap_conf_thresh
 };
 hipError_t launch_point_heads(const PointArgs& a, hipStream_t s);
 

@@ -29,6 +29,11 @@ class Engine(object):
         self.have_mano = False
         self.point_heads = False
         self.lanes = 0
+        self.conf_thresh = 0.35
+        self.center_idx = 9
+        self.temporal = False
+        self.comm_ranks = 0
+        self._mano_tables = {}
 
     def close(self):
         if self.ctx:
@@ -73,6 +78,50 @@ class Engine(object):
         _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_LANES, int(n)), self.ctx)
         self.lanes = int(n)
 
+    def set_conf_thresh(self, thresh):
+        """ACRMI_OPT_CONF_THRESH = args().centermap_conf_thresh (acr/result_parser.py:198-205,241; strict >)."""
+        _lib.check(self.L.acrmi_set_option_f(self.ctx, _lib.OPT_CONF_THRESH, float(thresh)), self.ctx)
+        self.conf_thresh = float(thresh)
+
+    def set_center_idx(self, idx):
+        """ACRMI_OPT_CENTER_IDX: root-alignment joint of the fused path (args().align_idx; None = no alignment,
+        acr/mano_wrapper.py:19-33)."""
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_CENTER_IDX, -1 if idx is None else int(idx)), self.ctx)
+        self.center_idx = idx
+
+    def set_temporal(self, on, smooth_coeff=None):
+        """ACRMI_OPT_TEMPORAL: `forward` smooths the decoded poses/betas on the device before MANO
+        (acr/main.py:69-83); the frames of a call are then one video stream in order."""
+        if smooth_coeff is not None:
+            _lib.check(self.L.acrmi_set_option_f(self.ctx, _lib.OPT_SMOOTH_COEFF, float(smooth_coeff)), self.ctx)
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_TEMPORAL, int(bool(on))), self.ctx)
+        self.temporal = bool(on)
+
+    def smooth(self, slots):
+        """One-Euro smoothing of slots [B,2,176] in place (acr/utils.py:1466-1527), state resident in the context."""
+        if not slots.is_cuda or slots.dtype != torch.float32 or not slots.is_contiguous():
+            raise ValueError('slots must be a contiguous float32 device tensor')
+        _lib.check(self.L.acrmi_smooth(self.ctx, _ptr(slots), slots.shape[0], _stream(self.device)), self.ctx)
+        return slots
+
+    def smooth_reset(self):
+        _lib.check(self.L.acrmi_smooth_reset(self.ctx, _stream(self.device)), self.ctx)
+
+    # ---- multi-GPU (SURVEY.md 8e) ----------------------------------------------------------------
+    def comm_init(self, n_ranks, rank, unique_id):
+        """acrmi_comm_init: RCCL communicator on this context's device (collective)."""
+        uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(self.L.acrmi_comm_init(self.ctx, int(n_ranks), int(rank), uid), self.ctx)
+        self.comm_ranks = int(n_ranks)
+
+    def allgather(self, send, recv, stream=None):
+        """acrmi_allgather of a flat float32 device tensor into recv [n_ranks * send.numel()]."""
+        if recv.numel() != self.comm_ranks * send.numel():
+            raise ValueError('recv must hold n_ranks * send.numel() floats')
+        st = _stream(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.L.acrmi_allgather(self.ctx, None, _ptr(send), _ptr(recv), send.numel(), st), self.ctx)
+        return recv
+
     def run_point_heads(self, B):
         """Re-evaluates the point heads on the resident buffers for the current center maps (acrmi_point_heads)."""
         _lib.check(self.L.acrmi_point_heads(self.ctx, B, _stream(self.device)), self.ctx)
@@ -88,7 +137,16 @@ class Engine(object):
         The left-hand shapedirs x-flip (acr/mano_wrapper.py:35) must already be applied by the caller."""
         for name in ('left', 'right'):
             self.load_mano_side(name, tables[name])
-        self.have_mano = True
+
+    def adopt(self, other):
+        """Takes over the MANO tables and options of an engine this one replaces (a checkpoint reload builds a new
+        context; MANOWrapper / callers keep working against the model's current engine)."""
+        for name, t in other._mano_tables.items():
+            self.load_mano_side(name, t)
+        self.set_conf_thresh(other.conf_thresh)
+        self.set_center_idx(other.center_idx)
+        if other.lanes:
+            self.set_lanes(other.lanes)
 
     def load_mano_side(self, name, t):
         """One side's tables (mano/manolayer.py:61-102 buffers) -> HBM, blend-shape tables transposed."""
@@ -102,6 +160,9 @@ class Engine(object):
         with torch.cuda.device(self.device):
             torch.cuda.synchronize()      # tables may be replaced while earlier launches still read them
             _lib.check(self.L.acrmi_load_mano(self.ctx, side, *[a.ctypes.data_as(C.c_void_p) for a in arrs]), self.ctx)
+        self._mano_tables[name] = {k: a for k, a in zip(('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights',
+                                                          'hands_mean'), arrs)}
+        self.have_mano = len(self._mano_tables) == 2
 
     # ---- hot path ------------------------------------------------------------------------------
     def _check_img(self, img):

@@ -81,8 +81,8 @@ def preprocess(bgr_frames):
     n, H, W, _ = bgr_frames.shape
     out = torch.empty(n, 512, 512, 3, dtype=torch.uint8, device=bgr_frames.device)
     offsets = np.zeros((n, 10), np.float32)
-    _lib.check(_lib.lib().acrmi_preprocess(_p(bgr_frames.contiguous()), n, H, W, _p(out),
-                                           offsets.ctypes.data_as(C.c_void_p), _s(bgr_frames)))
+    src = bgr_frames.contiguous()          # bound to a local until the call has been queued
+    _lib.check(_lib.lib().acrmi_preprocess(_p(src), n, H, W, _p(out), offsets.ctypes.data_as(C.c_void_p), _s(src)))
     return out, torch.from_numpy(offsets)
 
 
@@ -103,7 +103,8 @@ def u8norm(img):
     _need_cuda(img)
     B, H, W, _ = img.shape
     out = torch.empty(B, H, W, 4, dtype=torch.float32, device=img.device)
-    _lib.check(_lib.lib().acrmi_u8norm(_p(img.contiguous()), B * H * W, _p(out), _s(img)))
+    src = img.contiguous()                 # bound to a local until the call has been queued
+    _lib.check(_lib.lib().acrmi_u8norm(_p(src), B * H * W, _p(out), _s(src)))
     return out
 
 
@@ -139,12 +140,12 @@ def attpool(segm, feat, channels):
     return pooled
 
 
-def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior):
-    """NHWC device maps -> slots [B,2,176]."""
+def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior, conf_thresh=0.35):
+    """NHWC device maps -> slots [B,2,176].  conf_thresh = args().centermap_conf_thresh (strict >)."""
     _need_cuda(l_center, r_center, l_params, r_params, l_prior, r_prior)
     B = l_center.shape[0]
     slots = torch.empty(B, 2, _lib.SLOT, dtype=torch.float32, device=l_center.device)
     _lib.check(_lib.lib().acrmi_decode_maps(_p(l_center), _p(r_center), l_center.shape[-1], _p(l_params), _p(r_params),
                                             l_params.shape[-1], _p(l_prior), _p(r_prior), l_prior.shape[-1], B,
-                                            _p(slots), _s(slots)))
+                                            float(conf_thresh), _p(slots), _s(slots)))
     return slots

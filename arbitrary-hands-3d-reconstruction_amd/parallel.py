@@ -7,7 +7,16 @@ per-frame decode, per-hand MANO), so the only communication is the gather of res
 per frame 2 hands x (176 slot + 778*3 verts + 21*3 joints) floats = 20.6 KB.  Detections vary per
 frame, all-gather needs equal counts, hence fixed slots + a flag instead of the reference's
 variable-length "all left rows, then all right rows" (rebuilt on the host by rows_from_slots).
+
+Two transports for the same collective:
+  * `torch.distributed.all_gather_into_tensor` (backend nccl = RCCL; gloo in the CPU tests) - the default;
+  * the library's own `acrmi_allgather` (C ABI, ncclAllGather on a communicator created by
+    `acrmi_comm_init`; no torch.distributed on the data path) - `transport='c'` or ACRMI_GATHER=c.
+Either way the gather of batch k is queued on a side stream behind an event, into the second of two
+result buffers, so it overlaps batch k+1's backbone (`submit` / `collect`).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,38 +46,114 @@ def result_views(flat, n_frames):
             'joints': flat[b:].view(n_frames, 2, 21, 3)}
 
 
-def all_gather_results(flat_local, n_local, group=None):
-    """flat_local: this rank's alloc_result buffer.  Returns dict of [world*n_local, 2, ...] tensors in
-    global frame order (rank-major == frame order, because shards are contiguous)."""
-    world = dist.get_world_size(group)
-    gathered = torch.empty(world * flat_local.numel(), dtype=flat_local.dtype, device=flat_local.device)
-    dist.all_gather_into_tensor(gathered, flat_local, group=group)
+def split_gathered(gathered, world, n_local):
+    """[world * per-rank flat] -> dict of [world*n_local, 2, ...] tensors in global frame order (rank-major ==
+    frame order, because shards are contiguous)."""
     per_rank = gathered.view(world, -1)
     views = [result_views(per_rank[r], n_local) for r in range(world)]
     return {k: torch.cat([v[k] for v in views], 0) for k in ('slots', 'verts', 'joints')}
 
 
+def all_gather_results(flat_local, n_local, group=None):
+    """flat_local: this rank's alloc_result buffer.  Returns dict of [world*n_local, 2, ...] tensors."""
+    world = dist.get_world_size(group)
+    gathered = torch.empty(world * flat_local.numel(), dtype=flat_local.dtype, device=flat_local.device)
+    dist.all_gather_into_tensor(gathered, flat_local, group=group)
+    return split_gathered(gathered, world, n_local)
+
+
+def init_engine_comm(engine, group=None):
+    """Creates the engine's own RCCL communicator (acrmi_comm_init): rank 0 draws the 128-byte unique id and the
+    existing process group (any backend) carries it to the other ranks - the host's "own means" of include/acrmi.h."""
+    import ctypes as C
+    from . import _lib
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [None]
+    if rank == 0:
+        uid = (C.c_char * 128)()
+        _lib.check(_lib.lib().acrmi_comm_unique_id(uid))
+        box[0] = bytes(uid)
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(world, rank, box[0])
+
+
 class ShardedRunner(object):
     """Runs `local_forward(frames_local, out_views)` on this rank's shard and gathers every rank's results.
-    local_forward is Engine.forward on a GPU rank; tests substitute a CPU stand-in over gloo."""
+    local_forward is Engine.forward on a GPU rank; tests substitute a CPU stand-in over gloo.
 
-    def __init__(self, local_forward, device, group=None):
+    transport: 'torch' (torch.distributed) or 'c' (acrmi_allgather on `engine`'s communicator); default from
+    ACRMI_GATHER, else 'torch'."""
+
+    def __init__(self, local_forward, device, group=None, engine=None, transport=None):
         self.local_forward = local_forward
-        self.device = device
+        self.device = torch.device(device)
         self.group = group
-        self._buf = {}
+        self.engine = engine
+        self.transport = transport or os.environ.get('ACRMI_GATHER', 'torch')
+        if self.transport not in ('torch', 'c'):
+            raise ValueError("transport must be 'torch' or 'c'")
+        if self.transport == 'c':
+            if engine is None:
+                raise ValueError("transport 'c' needs the Engine whose context owns the communicator")
+            if not engine.comm_ranks:
+                init_engine_comm(engine, group)
+        self._buf = {}          # n_local -> two (flat, views, gathered) sets
+        self._turn = 0
+        self._comm_stream = None
+        self._pending = {}
 
-    def _result(self, n_local):
+    def _set(self, n_local, turn):
+        world = dist.get_world_size(self.group)
         if n_local not in self._buf:
-            self._buf[n_local] = alloc_result(n_local, self.device)
-        return self._buf[n_local]
+            sets = []
+            for _ in range(2):
+                flat, views = alloc_result(n_local, self.device)
+                sets.append((flat, views, torch.empty(world * flat.numel(), dtype=torch.float32, device=self.device)))
+            self._buf[n_local] = sets
+        return self._buf[n_local][turn]
+
+    def submit(self, frames_local):
+        """Queues forward + all-gather of this rank's shard; returns a ticket for collect().  At most two tickets
+        may be outstanding (double-buffered results)."""
+        n_local = frames_local.shape[0]
+        turn = self._turn
+        self._turn ^= 1
+        if turn in self._pending:
+            raise RuntimeError('collect() the ticket submitted two calls ago first (results are double-buffered)')
+        flat, views, gathered = self._set(n_local, turn)
+        self.local_forward(frames_local, views)
+        ticket = {'turn': turn, 'n_local': n_local, 'event': None, 'work': None}
+        if self.device.type == 'cuda':
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(self.device)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self._comm_stream.wait_event(done)             # the gather starts when this batch's MANO has finished
+            with torch.cuda.stream(self._comm_stream):
+                if self.transport == 'c':
+                    self.engine.allgather(flat, gathered, stream=self._comm_stream)
+                else:
+                    dist.all_gather_into_tensor(gathered, flat, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self._comm_stream)
+            ticket['event'] = ev
+        else:
+            dist.all_gather_into_tensor(gathered, flat, group=self.group)
+        self._pending[turn] = ticket
+        return ticket
+
+    def collect(self, ticket):
+        """Results of a submit(): the caller's current stream waits for the gather; returns global-order tensors."""
+        self._pending.pop(ticket['turn'], None)
+        if ticket['event'] is not None:
+            torch.cuda.current_stream(self.device).wait_event(ticket['event'])
+        _, _, gathered = self._set(ticket['n_local'], ticket['turn'])
+        return split_gathered(gathered, dist.get_world_size(self.group), ticket['n_local'])
 
     def forward_local(self, frames_local):
         """Weak-scaling entry: every rank already holds its own frames."""
-        n_local = frames_local.shape[0]
-        flat, views = self._result(n_local)
-        self.local_forward(frames_local, views)
-        return all_gather_results(flat, n_local, self.group)
+        return self.collect(self.submit(frames_local))
 
     def forward_global(self, frames_global):
         """Strong-scaling entry: every rank sees the global batch and takes its contiguous shard."""

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ACRMI_VERSION 100
+#define ACRMI_VERSION 200
 
 #define ACRMI_OK 0
 #define ACRMI_EINVAL (-1)  /* bad argument / unsupported shape  (reference: ValueError / assert) */
@@ -97,7 +97,7 @@ typedef struct {
 /* Fixed per-(frame,hand) result slot written by acrmi_decode: ACRMI_SLOT floats.
  * hand 0 = left, 1 = right (acr/result_parser.py:166-168 ordering is rebuilt on the host). */
 #define ACRMI_SLOT 176
-#define ACRMI_SLOT_FLAG 0      /* 1.0 if center score > 0.35 (strict)                      */
+#define ACRMI_SLOT_FLAG 0      /* 1.0 if center score > ACRMI_OPT_CONF_THRESH (strict)      */
 #define ACRMI_SLOT_FLATIND 1   /* y*64+x of the center (0 when not detected)               */
 #define ACRMI_SLOT_SCORE 2
 #define ACRMI_SLOT_CAM 3       /* 3  */
@@ -147,6 +147,7 @@ int acrmi_decode(acrmi_ctx* ctx, int B, float* slots_dev, void* stream);
 int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs,
                       const float* l_params, const float* r_params, int params_cs,
                       const float* l_prior, const float* r_prior, int prior_cs, int B,
+                      float conf_thresh /* CenterMap.conf_thresh = args().centermap_conf_thresh, 0.35 */,
                       float* slots_dev, void* stream);
 
 /* mano/manolayer.py:104-276 (ManoLayer.forward, use_pca=False, flat_hand_mean=False,
@@ -167,7 +168,8 @@ int acrmi_cam_trans(const float* joints_dev, const float* pj2d_dev, int n, float
                     float* trans_dev, void* stream);
 
 /* acr/main.py:126-141 + :85 in one call: frames -> slots [B,2,ACRMI_SLOT], verts [B,2,778,3],
- * joints [B,2,21,3] (root-aligned on joint 9, metres).  offsets_dev [B,10] may be NULL. */
+ * joints [B,2,21,3] (root-aligned on joint ACRMI_OPT_CENTER_IDX = 9, metres; threshold ACRMI_OPT_CONF_THRESH;
+ * smoothed when ACRMI_OPT_TEMPORAL).  offsets_dev [B,10] may be NULL. */
 int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* offsets_dev, float* slots_dev,
                   float* verts_dev, float* joints_dev, float* verts_camed_dev, float* pj2d_dev,
                   float* pj2d_org_dev, void* stream);
@@ -181,9 +183,10 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,
                  int algo, void* stream);
 /* acr/utils.py:1276-1337 (img_preprocess / image_pad_white_bg / cv2.resize INTER_CUBIC): n BGR uint8 frames
- * [n,H,W,3] on the device -> RGB uint8 [n,512,512,3] (white pad to square, bicubic a=-0.75, half-pixel
- * centres, replicate border).  offsets_host [n,10] (may be NULL) receives the reference's `offsets` rows
- * (padded h, padded w, crop trbl = 0, pad trbl). */
+ * [n,H,W,3] on the device -> RGB uint8 [n,512,512,3]: white pad to square (imgaug 0.4.0
+ * compute_paddings_to_reach_aspect_ratio + Pad), then OpenCV's uint8 INTER_CUBIC restated bit for bit (a = -0.75,
+ * 11-bit fixed-point coefficients, clamped border, (v + 2^21) >> 22; see oracle/preprocess.py).  offsets_host
+ * [n,10] (may be NULL) receives the reference's `offsets` rows (padded h, padded w, crop trbl = 0, pad trbl). */
 int acrmi_preprocess(const uint8_t* bgr_dev, int n, int H, int W, uint8_t* out_rgb_dev, float* offsets_host,
                      void* stream);
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
@@ -203,7 +206,40 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
  * stream-ordered operation.  0 = chosen by batch size (4 lanes up to 32 frames, 2 above), 1 = single stream.
  * Same kernels, bit-identical results. */
 #define ACRMI_OPT_LANES 2
+/* ACRMI_OPT_CENTER_IDX (-1..20, default 9): the joint acrmi_forward's MANO stage aligns the mesh root on
+ * (args().align_idx when args().mano_mesh_root_align, acr/mano_wrapper.py:19-33); -1 = no alignment. */
+#define ACRMI_OPT_CENTER_IDX 3
+/* ACRMI_OPT_TEMPORAL (0/1, default 0): acrmi_forward smooths the decoded poses/betas (acrmi_smooth) before MANO -
+ * the reference's -t / temporal_optimization (acr/main.py:69-83).  The frames of a call are then ONE video stream
+ * in order. */
+#define ACRMI_OPT_TEMPORAL 4
 int acrmi_set_option(acrmi_ctx* ctx, int option, int value);
+/* ACRMI_OPT_CONF_THRESH (default 0.35): center score threshold, strict > (args().centermap_conf_thresh,
+ * acr/result_parser.py:198-205,241).  ACRMI_OPT_SMOOTH_COEFF (default 4.0): One-Euro mincutoff of the pose filters
+ * (args().smooth_coeff, acr/main.py:45-47). */
+#define ACRMI_OPT_CONF_THRESH 5
+#define ACRMI_OPT_SMOOTH_COEFF 6
+int acrmi_set_option_f(acrmi_ctx* ctx, int option, float value);
+
+/* acr/main.py:69-83 + acr/utils.py:1466-1527 (smooth_results / OneEuroFilter / LowPassFilter): One-Euro smoothing
+ * of slots_dev [B,2,ACRMI_SLOT] in place - poses[3:48] and betas directly, the global orientation as a rotation
+ * matrix (acr/utils.py:1466-1470) - for the hands whose flag is set, frames in order, one filter set per hand type.
+ * The filter state of ONE video stream lives in the context; acrmi_smooth_reset starts a new stream. */
+int acrmi_smooth(acrmi_ctx* ctx, float* slots_dev, int B, void* stream);
+int acrmi_smooth_reset(acrmi_ctx* ctx, void* stream);
+
+/* Multi-GPU (replaces nn.DataParallel's scatter/gather, acr/main.py:61): frames are sharded by the caller, one
+ * process per GPU; the only collective is ONE all-gather per batch of each rank's flat result buffer
+ * [slots | verts | joints] over RCCL/xGMI.  recv_dev holds n_ranks * n_floats floats, rank-major.
+ * acrmi_comm_unique_id: 128-byte ncclUniqueId, created on rank 0 and handed to every rank by the host's own means;
+ * acrmi_comm_init: ncclCommInitRank on the context's device (collective: every rank calls it);
+ * acrmi_allgather: ncclAllGather on `stream`; nccl_comm = NULL uses the context's communicator, otherwise a
+ * caller-owned ncclComm_t.  RCCL is resolved at run time (dlopen); without it these calls return ACRMI_ESTATE. */
+int acrmi_comm_unique_id(void* id128_out);
+int acrmi_comm_init(acrmi_ctx* ctx, int n_ranks, int rank, const void* id128);
+int acrmi_comm_destroy(acrmi_ctx* ctx);
+int acrmi_allgather(acrmi_ctx* ctx, void* nccl_comm, const float* send_dev, float* recv_dev, size_t n_floats,
+                    void* stream);
 
 /* Runs only the point-heads ops on the resident buffers of the last acrmi_backbone_heads / acrmi_forward call:
  * params/cam/prior towers + mix (acr/model.py:71-99,160-164) at the centers of the CURRENT center maps, written

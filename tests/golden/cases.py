@@ -87,3 +87,30 @@ def sub(t, max_elems=4096):
     a = np.asarray(t, dtype=np.float32).reshape(-1)
     step = max(1, a.size // max_elems)
     return a[::step][:max_elems].copy(), np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+
+
+# ---- temporal smoothing sequence (G9) -----------------------------------------------------------------
+def smooth_inputs(n_frames=14, seed=41):
+    """A random-walk (poses [T,2,48], betas [T,2,10]) sequence for the two hand types plus per-frame detection
+    flags [T,2]: the right hand appears at frame 2, the left hand drops out for frames 6-7 (its filters then keep
+    their state, acr/main.py:78-80), a near-pi global orientation sits at frame 9."""
+    g = rng(seed)
+    poses = np.zeros((n_frames, 2, 48), np.float32)
+    betas = np.zeros((n_frames, 2, 10), np.float32)
+    p = g.normal(0, 0.5, (2, 48))
+    b = g.normal(0, 0.8, (2, 10))
+    for t in range(n_frames):
+        p = p + g.normal(0, 0.12, (2, 48))
+        b = b + g.normal(0, 0.05, (2, 10))
+        poses[t], betas[t] = p, b
+    poses[9, 0, :3] = [3.1, 0.02, -0.03]
+    flags = np.ones((n_frames, 2), bool)
+    flags[:2, 1] = False
+    flags[6:8, 0] = False
+    return poses, betas, flags
+
+
+# ---- network states through the real reference (G10): checkpoint seed -> detection state on synth frames --
+# (found by scanning seeds with the pinned oracle; seed 0 = both hands, centres 63 px apart, is e2e_batch1.npz)
+STATE_CHECKPOINTS = {'both_near': 10, 'left_only': 3, 'right_only': 11, 'none': 7}
+STATE_FRAME_SEED = 5

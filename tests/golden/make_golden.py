@@ -137,6 +137,67 @@ def main():
         org = ref_utils.convert_kp2d_from_input_to_orgimg(pj[:, :, :2], torch.from_numpy(offsets))
     mano['proj_verts_camed'], mano['proj_pj2d'], mano['proj_pj2d_org'] = vc.numpy(), pj.numpy(), org.numpy()
     np.savez_compressed(os.path.join(HERE, 'mano_cases.npz'), **mano)
+
+    # ---- G9: temporal smoothing sequence (acr/main.py:69-83 driving acr/utils.py:1466-1527) ----------
+    poses, betas, flags = cases.smooth_inputs()
+    filt = {0: ref_utils.create_OneEuroFilter(4.0), 1: ref_utils.create_OneEuroFilter(4.0)}
+    sp, sb = poses.copy(), betas.copy()
+    for t in range(poses.shape[0]):
+        for sid in range(2):                      # row index == hand type at batch 1 (acr/main.py:71-83)
+            if flags[t, sid]:
+                p, b = ref_utils.smooth_results(filt[sid], torch.from_numpy(poses[t, sid].copy()),
+                                                torch.from_numpy(betas[t, sid].copy()))
+                sp[t, sid], sb[t, sid] = p.numpy(), b.numpy()
+    np.savez_compressed(os.path.join(HERE, 'smooth_seq.npz'), poses=sp, betas=sb, smooth_coeff=np.float32(4.0))
+    print('smoothing: max |smoothed - raw| pose %.3f' % np.abs(sp - poses).max())
+
+    # ---- G10: detection states through the whole network (one checkpoint seed per state) ------------
+    st = {}
+    sframes = torch.from_numpy(synth.make_frames(2, seed=cases.STATE_FRAME_SEED))
+    for name, seed in cases.STATE_CHECKPOINTS.items():
+        model.load_state_dict(synth.make_state_dict(seed=seed), strict=True)
+        for b in range(2):
+            meta = {'image': sframes[b:b + 1], 'offsets': torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]),
+                    'batch_ids': torch.arange(1), 'imgpath': ['s%d' % b]}
+            with torch.no_grad():
+                o = model(meta, mode='parsing', calc_loss=False)
+                keys = ['params_pred', 'detection_flag', 'l_centers_pred', 'r_centers_pred', 'l_centers_conf',
+                        'r_centers_conf', 'output_hand_type']
+                if o['detection_flag'].sum() > 0:          # acr/main.py:96: MANO only runs when a hand was detected
+                    o = wrapper(o, o['meta_data'])
+                    keys += ['verts', 'j3d', 'pj2d', 'cam_trans']
+            for k in keys:
+                st['%s_f%d_%s' % (name, b, k)] = o[k].numpy()
+            for k in ('cam', 'poses', 'betas'):
+                st['%s_f%d_%s' % (name, b, k)] = o['params_dict'][k].numpy()
+        print('state', name, 'seed', seed, 'flags', st[name + '_f0_detection_flag'], st[name + '_f1_detection_flag'],
+              'centers', st[name + '_f0_l_centers_pred'].tolist(), st[name + '_f0_r_centers_pred'].tolist())
+    np.savez_compressed(os.path.join(HERE, 'e2e_states.npz'), **st)
+    model.load_state_dict(sd, strict=True)
+
+    # ---- G11: BASELINE configs[0] - demo/magic.jpg through the reference's img_preprocess + model + MANO --
+    # (cv2.imread is absent: the JPEG is decoded with PIL; cv2.resize / imgaug are the oracle's restatements, see
+    #  ref_shim.py.  tests/golden/magic.jpg is a byte copy of the reference's demo input - a data file.)
+    import shutil
+    from PIL import Image
+    src_jpg = os.path.join(ref_shim.REF, 'demo', 'magic.jpg')
+    shutil.copyfile(src_jpg, os.path.join(HERE, 'magic.jpg'))
+    os.chmod(os.path.join(HERE, 'magic.jpg'), 0o644)
+    bgr = np.ascontiguousarray(np.asarray(Image.open(src_jpg).convert('RGB'))[:, :, ::-1])
+    meta = ref_utils.img_preprocess(bgr, 'demo/magic.jpg', input_size=512, single_img_input=True)
+    meta['batch_ids'] = torch.arange(1)
+    mg = {'bgr_sum': np.array([bgr.astype(np.int64).sum(), (bgr.astype(np.int64) * (np.arange(bgr.size).reshape(bgr.shape) % 251)).sum()]),
+          'image_sub': meta['image'][0].numpy()[::4, ::4].copy(), 'offsets': meta['offsets'].numpy(),
+          'image_sum': np.array([meta['image'].numpy().astype(np.int64).sum()])}
+    meta['imgpath'] = ['demo/magic.jpg']
+    with torch.no_grad():
+        o = model(meta, mode='parsing', calc_loss=False)
+        o = wrapper(o, o['meta_data'])
+    for k in ('params_pred', 'detection_flag', 'verts', 'j3d', 'pj2d', 'pj2d_org', 'l_centers_pred', 'r_centers_pred',
+              'cam_trans'):
+        mg[k] = o[k].numpy()
+    np.savez_compressed(os.path.join(HERE, 'magic_e2e.npz'), **mg)
+    print('magic.jpg', bgr.shape, 'offsets', mg['offsets'].tolist(), 'flags', mg['detection_flag'])
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KB')

@@ -4,7 +4,8 @@ AUTHORING-CONTAINER ONLY.  Used by tests/golden/make_golden.py to capture golden
 vectors from the real reference and by nothing else; /root/reference does not
 exist on the GPU box.  The reference tree is never written to
 (PYTHONDONTWRITEBYTECODE, no ConfigContext/main()).  Shims:
-  * sys.modules stubs for cv2 / h5py / imgaug / chumpy (absent here, no network)
+  * sys.modules stubs for cv2 / h5py / imgaug / chumpy (absent here, no network); cv2.resize(INTER_CUBIC) and
+    imgaug's pad helpers are served by oracle/preprocess.py (their published algorithms restated)
   * sys.argv=['x'] before import (acr/config.py:232 parses argv at import)
   * Tensor.cuda / Module.cuda = identity (hard-coded .cuda() calls)
   * np.float / np.int aliases (acr/utils.py:493)
@@ -32,17 +33,48 @@ def import_reference(mano_tables=None):
         sys.modules[name] = m
         return m
 
+    # cv2 / imgaug are absent: the two calls the pre-processing makes (acr/utils.py:1294-1321) are served by the
+    # oracle's restatement of their published algorithms (oracle/preprocess.py), everything else stays a stub
+    from oracle import preprocess as opre
     if 'cv2' not in sys.modules:
-        stub('cv2')
+        def cv_resize(src, dsize, interpolation=None, **kw):
+            assert interpolation == 2, 'only INTER_CUBIC is restated'
+            return opre.resize_cubic_u8(np.ascontiguousarray(src), dsize[1], dsize[0])
+        stub('cv2', resize=cv_resize, INTER_CUBIC=2)
     if 'h5py' not in sys.modules:
         stub('h5py')
     if 'imgaug' not in sys.modules:
+        class _Pad(object):
+            def __init__(self, px=None, keep_size=False, pad_mode='constant', pad_cval=0):
+                assert not keep_size and pad_mode == 'constant'
+                self.px, self.cval = px, pad_cval
+
+            def __call__(self, image):
+                return opre.pad_trbl(image, self.px, self.cval)
+
+        class _Crop(object):
+            def __init__(self, px=None, keep_size=False):
+                assert not keep_size
+                self.px = px
+
+            def __call__(self, image):
+                t, r, b, l = self.px
+                return image[t:image.shape[0] - b, l:image.shape[1] - r]
+
+        class _Sequential(object):
+            def __init__(self, children):
+                self.children = children
+
+            def __call__(self, image=None):
+                for c in self.children:
+                    image = c(image)
+                return image
         ia = stub('imgaug')
-        iaa = stub('imgaug.augmenters',
-                   compute_paddings_to_reach_aspect_ratio=lambda *a, **k: (0, 0, 0, 0))
+        iaa = stub('imgaug.augmenters', Pad=_Pad, Crop=_Crop, Sequential=_Sequential,
+                   compute_paddings_to_reach_aspect_ratio=opre.compute_paddings_to_reach_aspect_ratio)
         ia.augmenters = iaa
         size = stub('imgaug.augmenters.size',
-                    compute_paddings_to_reach_aspect_ratio=lambda *a, **k: (0, 0, 0, 0))
+                    compute_paddings_to_reach_aspect_ratio=opre.compute_paddings_to_reach_aspect_ratio)
         iaa.size = size
     if 'chumpy' not in sys.modules:
         class Ch(object):

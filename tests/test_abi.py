@@ -21,11 +21,13 @@ def test_library_exports_every_declared_symbol():
     L = pkg('_lib')
     lib = L.lib()
     declared = _declared_symbols()
-    assert len(declared) >= 19
+    assert len(declared) >= 31
     for name in declared:
         assert hasattr(lib, name), 'libacrmi.so does not export %s' % name
     assert sorted(L.EXPORTS) == declared
-    assert lib.acrmi_version() == 100
+    assert lib.acrmi_version() == L.VERSION == 200
+    for name in ('acrmi_allgather', 'acrmi_comm_init', 'acrmi_smooth', 'acrmi_set_option_f'):      # SURVEY.md 8b list
+        assert name in declared
 
 
 def test_struct_layout_matches_header():
@@ -57,3 +59,9 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert lib.acrmi_load_weights(None, None, 0) == L.E_INVAL
     assert lib.acrmi_decode(None, 1, None, None) == L.E_INVAL
     assert lib.acrmi_conv2d(None, 1, 8, 8, 8, 0, 8, None, None, 0, None, 0, 0, None, 8, 0, 8, 3, 1, 0, 1, 0, None) == L.E_INVAL
+    assert lib.acrmi_smooth(None, None, 1, None) == L.E_INVAL
+    assert lib.acrmi_set_option_f(None, L.OPT_CONF_THRESH, 0.5) == L.E_INVAL
+    assert lib.acrmi_allgather(None, None, None, None, 0, None) == L.E_INVAL
+    assert lib.acrmi_comm_unique_id(None) == L.E_INVAL
+    assert lib.acrmi_comm_init(None, 1, 0, None) == L.E_INVAL
+    assert lib.acrmi_decode_maps(None, None, 4, None, None, 112, None, None, 108, 1, 0.35, None, None) == L.E_INVAL

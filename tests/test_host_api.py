@@ -111,34 +111,31 @@ def test_lowering_accounts_for_every_flop_and_rejects_bad_checkpoints(synth_sd):
         packer.lower(bad)
 
 
-def test_img_preprocess_offsets_and_identity_resize():
+def test_pad_geometry_matches_imgaug_rule():
+    """The host-side geometry helper (acr.utils) == the oracle's imgaug 0.4.0 restatement; the pixels themselves
+    only ever come from the HIP kernel (img_preprocess refuses to run without a GPU)."""
+    from oracle import preprocess as opre
     u = pkg('acr.utils')
-    bgr = np.random.RandomState(0).randint(0, 256, (512, 512, 3), dtype=np.uint8)
-    d = u.img_preprocess(bgr, 'x.jpg', single_img_input=True)
-    assert d['image'].dtype == torch.uint8 and tuple(d['image'].shape) == (1, 512, 512, 3)
-    assert np.array_equal(d['image'][0].numpy(), bgr[:, :, ::-1])               # BGR->RGB, 512->512 is exact
-    assert d['offsets'][0].tolist() == [512, 512, 0, 0, 0, 0, 0, 0, 0, 0]
-    wide = np.zeros((1080, 1920, 3), np.uint8)
-    d = u.img_preprocess(wide, None, single_img_input=True)
-    assert d['offsets'][0].tolist() == [1920, 1920, 0, 0, 0, 0, 420, 0, 420, 0]
-    assert (d['image'][0, :100] == 255).all() and (d['image'][0, 200:300] == 0).all()   # white pad, black frame
+    for shape in ((1080, 1920, 3), (480, 640, 3), (700, 301, 3), (301, 700, 3), (512, 512, 3), (333, 1000, 3)):
+        assert u.compute_paddings_to_reach_aspect_ratio(shape) == opre.compute_paddings_to_reach_aspect_ratio(shape)
+    if not torch.cuda.is_available():
+        with pytest.raises(pkg('_lib').AcrmiError):
+            u.img_preprocess(np.zeros((8, 8, 3), np.uint8), 'x.jpg', single_img_input=True)
+    with pytest.raises(ValueError):
+        u.img_preprocess(np.zeros((8, 8, 3), np.float32))
 
 
-def test_one_euro_filter_and_smoothing():
-    u = pkg('acr.utils')
-    f = u.create_OneEuroFilter(4.0)
-    pose = torch.randn(48) * 0.3
-    p1, b1 = u.smooth_results(f, pose.clone(), torch.zeros(10))
-    assert torch.allclose(p1, pose, atol=1e-5)                                  # first sample passes through
-    p2, _ = u.smooth_results(f, pose + 0.5, torch.zeros(10))
-    assert ((p2[3:] - pose[3:]) > 0).all() and ((p2[3:] - pose[3:]) < 0.5).all()    # low-pass between samples
-
-
-def test_estimate_translation_matches_reference_fallback():
-    g = golden('e2e_batch1.npz')
-    u = pkg('acr.utils')
-    t = u.estimate_translation(torch.from_numpy(g['f0_j3d']), torch.from_numpy(g['f0_pj2d']), focal_length=1265)
-    np.testing.assert_allclose(t.numpy(), g['f0_cam_trans'], rtol=2e-3, atol=2e-3)
+def test_config_plumbed_and_rejected_options():
+    """flags the kernels honour are accepted (centermap_conf_thresh, align_idx, mano_mesh_root_align,
+    smooth_coeff); flags they cannot honour raise instead of being silently ignored."""
+    cfg = pkg('config')
+    base = ['--configs_yml', '/nonexistent.yml']
+    ns = cfg.parse_args(base + ['--centermap_conf_thresh', '0.2', '--align_idx', '0', '--mano_mesh_root_align', 'false',
+                                '--smooth_coeff', '3.0'])
+    assert ns.centermap_conf_thresh == 0.2 and ns.align_idx == 0 and ns.mano_mesh_root_align is False
+    for bad in (['--kernel_sizes', '3'], ['--kernel_sizes', '5', '7'], ['--max_hand', '4'], ['--align_idx', '21']):
+        with pytest.raises(ValueError):
+            cfg.parse_args(base + bad)
 
 
 def test_state_dict_surface_without_gpu(synth_sd):

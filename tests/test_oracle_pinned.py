@@ -132,3 +132,109 @@ def test_end_to_end_batch1_matches_reference(synth_sd, frames2, mano_tables):
         _close(vc, g['f%d_verts_camed' % b], 1e-4, 1e-4)
         _close(pj, g['f%d_pj2d' % b], 1e-4, 1e-4)
         _close(org, g['f%d_pj2d_org' % b], 1e-4, 2e-2)
+
+
+# ---- round 2: detection states, temporal smoothing, cam_trans, pre-processing ------------------------------
+@pytest.mark.parametrize('name', list(cases.STATE_CHECKPOINTS))
+def test_network_states_match_reference(name, mano_tables):
+    """Left-only / right-only / none / both-with-prior through the WHOLE network (one checkpoint seed per state,
+    tests/golden/cases.py) == what the real reference produced at batch 1 (e2e_states.npz)."""
+    g = golden('e2e_states.npz')
+    torch.set_num_threads(8)
+    sd = pkg('synth').make_state_dict(seed=cases.STATE_CHECKPOINTS[name])
+    frames = torch.from_numpy(pkg('synth').make_frames(2, seed=cases.STATE_FRAME_SEED))
+    with torch.no_grad():
+        heads = acr_net.network(sd, frames)
+    slots = odec.decode(heads)
+    for b in range(2):
+        rows = odec.slots_to_rows({k: v[b:b + 1] for k, v in slots.items()})
+        key = '%s_f%d_' % (name, b)
+        np.testing.assert_array_equal(rows['detection_flag'], g[key + 'detection_flag'].astype(bool))
+        lc, rc = g[key + 'l_centers_pred'][0], g[key + 'r_centers_pred'][0]
+        assert rows['flat_ind'][0] == lc[1] * 64 + lc[0] and rows['flat_ind'][1] == rc[1] * 64 + rc[0]
+        _close(rows['params_pred'], g[key + 'params_pred'], 2e-4, 2e-4)
+        if name == 'none':
+            assert key + 'verts' not in g.files        # acr/main.py:96: MANO is not run when nothing is detected
+            continue
+        vl, jl, _ = omano.mano_forward(_tables(mano_tables, 'l'), 'left', rows['poses'][:1], rows['betas'][:1])
+        vr, jr, _ = omano.mano_forward(_tables(mano_tables, 'r'), 'right', rows['poses'][1:], rows['betas'][1:])
+        assert np.abs(np.concatenate([vl, vr]) - g[key + 'verts']).max() < 2e-5
+        assert np.abs(np.concatenate([jl, jr]) - g[key + 'j3d']).max() < 2e-5
+    if name == 'both_near':                            # the cross-hand prior was applied (distance <= 32 px)
+        lc, rc = g['both_near_f0_l_centers_pred'][0], g['both_near_f0_r_centers_pred'][0]
+        assert np.hypot(*(lc - rc).astype(float)) <= 32
+
+
+def test_smoothing_oracle_matches_reference_sequence():
+    """oracle.smooth (numpy f32) == the reference's smooth_results / OneEuroFilter over a 14-frame two-hand sequence
+    with a late-appearing hand, a two-frame drop-out and a near-pi global orientation (smooth_seq.npz)."""
+    from oracle import smooth as osm
+    g = golden('smooth_seq.npz')
+    poses, betas, flags = cases.smooth_inputs()
+    filt = {0: osm.new_filters(float(g['smooth_coeff'])), 1: osm.new_filters(float(g['smooth_coeff']))}
+    worst = 0.0
+    for t in range(poses.shape[0]):
+        for sid in range(2):
+            want_p, want_b = g['poses'][t, sid], g['betas'][t, sid]
+            if flags[t, sid]:
+                p, b = osm.smooth_results(filt[sid], poses[t, sid], betas[t, sid])
+            else:
+                p, b = poses[t, sid], betas[t, sid]
+            worst = max(worst, float(np.abs(p - want_p).max()), float(np.abs(b - want_b).max()))
+    assert worst < 2e-6, worst
+    assert np.abs(g['poses'][5] - poses[5]).max() > 1e-2       # the filter does something
+
+
+def test_cam_trans_oracle_matches_reference_fallback():
+    """oracle.smooth.estimate_translation == the reference's closed-form branch (acr/utils.py:430-472), which is what
+    the reference itself ran when e2e_batch1.npz was captured (cv2 absent -> bare except, acr/utils.py:512-517)."""
+    from oracle import smooth as osm
+    for name, key in (('e2e_batch1.npz', 'f0_'), ('e2e_states.npz', 'both_near_f1_')):
+        g = golden(name)
+        t = osm.estimate_translation(g[key + 'j3d'], g[key + 'pj2d'], focal_length=1265)
+        np.testing.assert_allclose(t, g[key + 'cam_trans'], rtol=1e-4, atol=1e-4)
+
+
+def test_preprocess_oracle_magic_jpg():
+    """BASELINE configs[0]: demo/magic.jpg -> img_preprocess.  The fixture was produced by the reference's own
+    img_preprocess (acr/utils.py:1315-1337) with cv2.resize / imgaug served by oracle/preprocess.py."""
+    from PIL import Image
+    from oracle import preprocess as opre
+    g = golden('magic_e2e.npz')
+    bgr = np.ascontiguousarray(np.asarray(Image.open(os.path.join(GOLDEN, 'magic.jpg')).convert('RGB'))[:, :, ::-1])
+    chk = np.array([bgr.astype(np.int64).sum(), (bgr.astype(np.int64) * (np.arange(bgr.size).reshape(bgr.shape) % 251)).sum()])
+    np.testing.assert_array_equal(chk, g['bgr_sum'])           # same JPEG decode as in the authoring container
+    img, offsets = opre.img_preprocess(bgr)
+    np.testing.assert_array_equal(offsets[None], g['offsets'])
+    assert offsets.tolist() == [1920, 1920, 0, 0, 0, 0, 420, 0, 420, 0]      # SURVEY.md 8d config 4 geometry
+    np.testing.assert_array_equal(img[::4, ::4], g['image_sub'])
+    assert int(img.astype(np.int64).sum()) == int(g['image_sum'][0])
+    assert (img[:100] == 255).all()                            # white pad rows (420 px of 1920 -> 112 of 512)
+
+
+def test_cubic_resize_oracle_properties():
+    """OpenCV's fixed-point INTER_CUBIC as restated in oracle/preprocess.py: identity at scale 1, constants stay
+    constant, coefficient rows sum to 2048 +- rounding, and the result stays within 1 LSB of a float bicubic
+    (a = -0.75, half-pixel centres, clamped border) on smooth content."""
+    from oracle import preprocess as opre
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(opre.resize_cubic_u8(img, 64, 64), img)
+    flat = np.full((90, 70, 3), 137, np.uint8)
+    assert (opre.resize_cubic_u8(flat, 32, 32) == 137).all()
+    s, c = opre._taps(1920, 512)
+    assert np.abs(c.sum(1) - 2048).max() <= 2 and s.min() == 1 and s.max() == 1917
+    yy, xx = np.mgrid[0:300, 0:420].astype(np.float32)
+    smooth = np.stack([127 + 100 * np.sin(xx / 23) * np.cos(yy / 31), 127 + 90 * np.cos(xx / 17 + yy / 29),
+                       (xx + yy) / 3], -1)
+    smooth = np.clip(smooth, 0, 255).astype(np.uint8)
+    got = opre.resize_cubic_u8(smooth, 128, 128)
+    x = torch.from_numpy(smooth).permute(2, 0, 1)[None].float()
+    ref = torch.nn.functional.interpolate(x, size=(128, 128), mode='bicubic', align_corners=False)
+    ref = ref.round().clamp(0, 255)[0].permute(1, 2, 0).numpy()
+    assert np.abs(got.astype(np.float32) - ref).max() <= 1
+    # imgaug 0.4.0 padding rule: the extra pixel goes to bottom / right
+    assert opre.compute_paddings_to_reach_aspect_ratio((1080, 1920, 3)) == (420, 0, 420, 0)
+    assert opre.compute_paddings_to_reach_aspect_ratio((701, 300, 3)) == (0, 201, 0, 200)
+    assert opre.compute_paddings_to_reach_aspect_ratio((300, 701, 3)) == (200, 0, 201, 0)
+    assert opre.compute_paddings_to_reach_aspect_ratio((512, 512, 3)) == (0, 0, 0, 0)
