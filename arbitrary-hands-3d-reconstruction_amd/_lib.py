@@ -42,7 +42,7 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
            'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
-           'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather']
+           'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias']
 
 _lib = None
 
@@ -98,6 +98,7 @@ def lib():
     L.acrmi_comm_init.argtypes = [vp, i32, i32, vp]
     L.acrmi_comm_destroy.argtypes = [vp]
     L.acrmi_allgather.argtypes = [vp, vp, f32p, f32p, C.c_size_t, vp]
+    L.acrmi_parebias.argtypes = [f32p, i32, i32, f32p, f32p, f32p, f32p, f32p, i32, f32p, i32, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr'):

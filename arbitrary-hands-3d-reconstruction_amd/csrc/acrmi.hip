@@ -900,6 +900,18 @@ int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "attpool: %s", hipGetErrorString(e));
 }
 
+int acrmi_parebias(const float* pooled, int C, int part0, const float* lc_w, const float* lin_w, const float* lin_b,
+                   const float* mix_wp, const float* mix_b, int B, float* out, int out_stride, void* stream) {
+  if (!pooled || !lc_w || !lin_w || !lin_b || !mix_wp || !mix_b || !out || B <= 0 || (C != 256 && C != 320) ||
+      (part0 != 0 && part0 != 16) || out_stride < 109 || out_stride > 256)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_parebias: bad arguments");
+  PareArgs a{};
+  a.pooled = pooled; a.lc_w = lc_w; a.lin_w = lin_w; a.lin_b = lin_b; a.mix_wp = mix_wp; a.mix_b = mix_b;
+  a.out = out; a.B = B; a.C = C; a.part0 = part0; a.out_stride = out_stride;
+  hipError_t e = launch_parebias(a, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "parebias: %s", hipGetErrorString(e));
+}
+
 int acrmi_cam_trans(const float* joints_dev, const float* pj2d_dev, int n, float focal_length, float img_size,
                     float* trans_dev, void* stream) {
   if (n < 0 || (n > 0 && (!joints_dev || !pj2d_dev || !trans_dev)) || !(focal_length > 0.f) || !(img_size > 0.f))

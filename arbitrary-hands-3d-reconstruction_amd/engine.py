@@ -47,9 +47,10 @@ class Engine(object):
             pass
 
     # ---- setup ---------------------------------------------------------------------------------
-    def load_state_dict(self, sd, max_batch=1):
-        """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights."""
-        prog = packer.lower(sd)
+    def load_state_dict(self, sd, max_batch=1, keep_taps=False):
+        """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
+        keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`)."""
+        prog = packer.lower(sd, keep_taps=keep_taps)
         blob = prog['blob']
         _lib.check(self.L.acrmi_load_weights(self.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), self.ctx)
         self.program = prog

@@ -140,6 +140,21 @@ def attpool(segm, feat, channels):
     return pooled
 
 
+def parebias(pooled, lc_w, lin_w, lin_b, mix_wp, mix_b, part0):
+    """pooled [B,32,C] device (C = 320: contact 256 | shape 64) + the reference's raw weights (host arrays:
+    contact_layers.{2,3}.weight -> [6,256,16], cam_shape_layers.{2,3} -> [10,1024] / [10], the pare columns of
+    contact_layers.{4,5} -> [109,106] / bias [109]) -> per-frame mix-conv bias [B,112] (acr/model.py:141-164)."""
+    _need_cuda(pooled)
+    B, _, Cc = pooled.shape
+    dev = pooled.device
+    w = [torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.float32))).to(dev) for a in (lc_w, lin_w, lin_b, mix_wp, mix_b)]
+    out = torch.zeros(B, 112, dtype=torch.float32, device=dev)
+    src = pooled.contiguous().float()
+    _lib.check(_lib.lib().acrmi_parebias(_p(src), Cc, int(part0), _p(w[0]), _p(w[1]), _p(w[2]), _p(w[3]), _p(w[4]), B,
+                                         _p(out), 112, _s(src)))
+    return out
+
+
 def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior, conf_thresh=0.35):
     """NHWC device maps -> slots [B,2,176].  conf_thresh = args().centermap_conf_thresh (strict >)."""
     _need_cuda(l_center, r_center, l_params, r_params, l_prior, r_prior)

@@ -148,6 +148,12 @@ class Program(object):
                 assert i not in self.free.setdefault((h, w, cs), []), 'double release of buffer %d' % i
                 self.free[(h, w, cs)].append(i)
 
+    def pin(self, i):
+        """Excludes buffer i from lifetime-based reuse from now on (its contents survive the whole program)."""
+        h, w, cs, _ = self.bufs[i]
+        self.bufs[i] = (h, w, cs, 1)
+        return i
+
     def dims(self, i):
         return self.bufs[i][:3]
 
@@ -326,9 +332,11 @@ def point_tower(P, side, k):
     return out
 
 
-def lower(sd, check=True, point_heads=True):
-    """state dict -> dict(blob, bufs, ops, heads, op_info).  See module docstring.
-    point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT)."""
+def lower(sd, check=True, point_heads=True, keep_taps=False):
+    """state dict -> dict(blob, bufs, ops, heads, op_info, taps).  See module docstring.
+    point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT).
+    keep_taps: pin the buffers of the backbone taps the golden vectors hold (stem / layer1 / stage2 / stage3 branch 0,
+    tests/golden/make_golden.py) so a test can read them after the run; costs ~0.6 GB at batch 64, off by default."""
     sd = strip_prefix(sd)
     if check:
         check_state_dict(sd)
@@ -344,8 +352,13 @@ def lower(sd, check=True, point_heads=True):
     x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True)
     P.release(x)
     x = x1
+    taps = {}
+    if keep_taps:
+        taps['stem'] = P.pin(x)
     for i in range(4):
         x = P.bottleneck(x, b + 'layer1.%d' % i)
+    if keep_taps:
+        taps['layer1'] = P.pin(x)
     # ---- stages ---------------------------------------------------------------------------------
     t = b + 'transition1'
     xs = [P.conv_bn(x, t + '.0.0', t + '.0.1', 3, 1, True), P.conv_bn(x, t + '.1.0.0', t + '.1.0.1', 3, 2, True)]
@@ -363,6 +376,8 @@ def lower(sd, check=True, point_heads=True):
             last = (s == 4 and m == nmod - 1)
             xs = P.hr_module(xs, b + 'stage%d.%d' % (s, m), ch, multi_scale=not last,
                              final_out=x34 if last else None)
+        if keep_taps and s < 4:
+            taps['stage%d' % s] = P.pin(xs[0])
     # ---- part-segmentation head (acr/model.py:374-463) ------------------------------------------
     u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
     g = b + 'hand_segm.segm_head.segm_net.double_conv'
@@ -491,4 +506,4 @@ def lower(sd, check=True, point_heads=True):
                   w_off2=P.blob.add(mixw))
         heads.params_buf[si] = final[side]
     heads.segm_buf, heads.backbone_buf = segm, x34
-    return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info}
+    return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info, 'taps': taps}

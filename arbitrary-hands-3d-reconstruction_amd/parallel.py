@@ -118,9 +118,9 @@ class ShardedRunner(object):
         may be outstanding (double-buffered results)."""
         n_local = frames_local.shape[0]
         turn = self._turn
-        self._turn ^= 1
         if turn in self._pending:
             raise RuntimeError('collect() the ticket submitted two calls ago first (results are double-buffered)')
+        self._turn ^= 1
         flat, views, gathered = self._set(n_local, turn)
         self.local_forward(frames_local, views)
         ticket = {'turn': turn, 'n_local': n_local, 'event': None, 'work': None}

@@ -195,6 +195,13 @@ int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, co
                    int W, int C, float* out, int out_cs, int relu, void* stream);
 int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* stats_ws,
                   float* pooled, void* stream);
+/* acr/model.py:141-164 per frame and hand: LocallyConnected2d (:559-569) on the 16 pooled part features of this side
+ * (parts part0..part0+15 of pooled [B,32,C]; C = 320: 256 contact + 64 shape channels as the reference pools them),
+ * the shape Linear, and the mix conv's pare columns: out[b][co] = mix_b[co] + sum_k mix_wp[co][k] * pare[k],
+ * pare = [offsets 96 | shape 10].  lc_w [6][256][16], lin_w [10][(C==320 ? 64 : 256)*16], mix_wp [109][106]. */
+int acrmi_parebias(const float* pooled_dev, int C, int part0, const float* lc_w_dev, const float* lin_w_dev,
+                   const float* lin_b_dev, const float* mix_wp_dev, const float* mix_b_dev, int B, float* out_dev,
+                   int out_stride, void* stream);
 
 /* Options.  ACRMI_OPT_POINT_HEADS (0/1, default 0): acrmi_forward evaluates the params/cam/prior head towers and
  * the mix conv only at the pixels the decode samples (same slots/vertices within fp32 round-off; the dense

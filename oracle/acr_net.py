@@ -140,6 +140,18 @@ def locally_connected(weight, x):
     return (x.unsqueeze(1).unsqueeze(-1) * weight).sum([2, -1])
 
 
+def pare_vector(sd, side, pooled_contact, pooled_shape):
+    """acr/model.py:141-159 for one side: pooled_contact [B,256,32,1], pooled_shape [B,64,32] ->
+    pare = [LocallyConnected2d offsets (96) | shape Linear (10)]  [B,106]."""
+    sl, lc = (slice(16, 32), 2) if side == 'l' else (slice(0, 16), 3)
+    B = pooled_contact.shape[0]
+    off = locally_connected(sd['contact_layers.%d.weight' % lc], pooled_contact[:, :, sl, :])
+    off = off.squeeze(-1).transpose(2, 1).reshape(B, 96)
+    shp = F.linear(torch.flatten(pooled_shape[:, :, sl], start_dim=1),
+                   sd['cam_shape_layers.%d.weight' % lc], sd['cam_shape_layers.%d.bias' % lc])
+    return torch.cat((off, shp), 1)
+
+
 def head_forward(sd, x, taps=None):
     """acr/model.py:47-166.  x: backbone output [B,32,128,128].  Returns the H11 dict."""
     B = x.shape[0]
@@ -164,12 +176,8 @@ def head_forward(sd, x, taps=None):
         taps['pooled_contact'] = wc[..., 0]
         taps['pooled_shape'] = ws
     out = {}
-    for side, sl, lc, lin, mix in (('l', slice(16, 32), 2, 2, 4), ('r', slice(0, 16), 3, 3, 5)):
-        off = locally_connected(sd['contact_layers.%d.weight' % lc], wc[:, :, sl, :])
-        off = off.squeeze(-1).transpose(2, 1).reshape(B, 96)
-        shp = F.linear(torch.flatten(ws[:, :, sl], start_dim=1),
-                       sd['cam_shape_layers.%d.weight' % lin], sd['cam_shape_layers.%d.bias' % lin])
-        pare = torch.cat((off, shp), 1)
+    for side, mix in (('l', 4), ('r', 5)):
+        pare = pare_vector(sd, side, wc, ws)
         if taps is not None:
             taps[side + '_pare'] = pare
         pm, center, prior = maps[side]

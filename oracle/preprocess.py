@@ -79,19 +79,24 @@ def resize_cubic_u8(image, out_h, out_w):
     H, W, _ = image.shape
     sx, ax = _taps(W, out_w)
     sy, ay = _taps(H, out_h)
-    src = image.astype(np.int32)
+    # (integer tensor arithmetic on torch-CPU: exact, and threaded - a 1920x1920 frame takes ~0.1 s instead of seconds)
+    import torch
+    src = torch.from_numpy(image)
     # horizontal pass: int32 rows, columns clamped to the border
-    hor = np.zeros((H, out_w, image.shape[2]), np.int32)
+    cols = torch.from_numpy(np.clip(sx[:, None] - 1 + np.arange(4)[None, :], 0, W - 1))      # [out_w, 4]
+    tx = torch.from_numpy(ax)                                                                 # [out_w, 4] int32
+    hor = torch.zeros(H, out_w, image.shape[2], dtype=torch.int32)
     for k in range(4):
-        cols = np.clip(sx - 1 + k, 0, W - 1)
-        hor += src[:, cols, :] * ax[:, k][None, :, None]
-    # vertical pass: rows clamped, FixedPtCast<int, uchar, 22>: (v + (1 << 21)) >> 22, saturate to [0, 255]
-    acc = np.zeros((out_h, out_w, image.shape[2]), np.int64)
+        hor += src[:, cols[:, k], :].to(torch.int32) * tx[:, k].view(1, -1, 1)
+    # vertical pass: rows clamped; OpenCV accumulates in int (no overflow for uint8 input: checked in int64)
+    rows = torch.from_numpy(np.clip(sy[:, None] - 1 + np.arange(4)[None, :], 0, H - 1))      # [out_h, 4]
+    ty = torch.from_numpy(ay).to(torch.int64)
+    acc = torch.zeros(out_h, out_w, image.shape[2], dtype=torch.int64)
     for k in range(4):
-        rows = np.clip(sy - 1 + k, 0, H - 1)
-        acc += hor[rows].astype(np.int64) * ay[:, k][:, None, None]
-    acc32 = acc.astype(np.int32)                            # OpenCV accumulates in int (no overflow for uint8 input)
-    assert np.array_equal(acc32.astype(np.int64), acc)
+        acc += hor[rows[:, k]].to(torch.int64) * ty[:, k].view(-1, 1, 1)
+    assert int(acc.abs().max()) < 2 ** 31 - 2 ** 21
+    acc32 = acc.numpy().astype(np.int32)
+    # FixedPtCast<int, uchar, 22>: (v + (1 << 21)) >> 22, saturate to [0, 255]
     shift = 2 * INTER_RESIZE_COEF_BITS
     out = (acc32 + (1 << (shift - 1))) >> shift
     return np.clip(out, 0, 255).astype(np.uint8)

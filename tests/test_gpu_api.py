@@ -103,7 +103,8 @@ def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
 
 def test_cam_trans_kernel_matches_reference_least_squares():
     """§8f-3: acrmi_cam_trans == the reference's closed-form least squares (acr/utils.py:430-472; restated in numpy
-    fp64 in acr.utils.estimate_translation_np and pinned against the reference's cam_trans in test_host_api)."""
+    fp64 in oracle/smooth.py and pinned against the reference's cam_trans in test_oracle_pinned)."""
+    from oracle import smooth as osm
     u, ops = pkg('acr.utils'), pkg('ops')
     rs = np.random.RandomState(3)
     n = 37
@@ -112,8 +113,8 @@ def test_cam_trans_kernel_matches_reference_least_squares():
     f = 1265.0
     p = j3.astype(np.float64) + t_true[:, None]
     pj2d = ((f * p[..., :2] / p[..., 2:] + 256) / 256 - 1 + rs.randn(n, 21, 2) * 2e-3).astype(np.float32)
-    want = np.stack([u.estimate_translation_np(j3[i].astype(np.float64), (pj2d[i].astype(np.float64) + 1) * 256,
-                                               np.ones(21, np.float32), focal_length=f) for i in range(n)])
+    want = np.stack([osm.estimate_translation_np(j3[i].astype(np.float64), (pj2d[i].astype(np.float64) + 1) * 256,
+                                                 np.ones(21, np.float32), focal_length=f) for i in range(n)])
     got = ops.cam_trans(torch.from_numpy(j3).cuda(), torch.from_numpy(pj2d).cuda(), focal_length=f).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
     assert np.abs(got - t_true).max() < 0.05                       # and it recovers the translation
@@ -123,20 +124,252 @@ def test_cam_trans_kernel_matches_reference_least_squares():
     assert t2.is_cuda and np.allclose(t2.cpu().numpy(), got)
 
 
-def test_gpu_preprocess_matches_host_preprocess():
-    """§8f-1: the HIP pre-processing kernel == acr.utils.img_preprocess (white pad + bicubic a=-0.75) on the same
-    frames; cv2 itself is not available here, so parity with OpenCV's fixed-point INTER_CUBIC stays unpinned."""
-    u, ops = pkg('acr.utils'), pkg('ops')
+def _blocky(rs, H, W):
+    base = rs.randint(0, 256, (H // 8 + 2, W // 8 + 2, 3)).astype(np.float32)
+    frame = np.kron(base, np.ones((8, 8, 1), np.float32))[:H, :W] + rs.randint(-9, 10, (H, W, 3))
+    return np.clip(frame, 0, 255).astype(np.uint8)
+
+
+def test_gpu_preprocess_is_bit_exact_to_the_opencv_restatement():
+    """§8f-1: acrmi_preprocess == oracle/preprocess.py (imgaug 0.4.0 pad rule + OpenCV's uint8 fixed-point
+    INTER_CUBIC restated from its published source) bit for bit, on up- and down-scaling, tall and wide frames."""
+    from oracle import preprocess as opre
+    ops = pkg('ops')
     rs = np.random.RandomState(4)
-    for H, W in ((1080, 1920), (480, 640), (700, 300), (512, 512), (333, 333)):
-        base = rs.randint(0, 256, (H // 8 + 2, W // 8 + 2, 3)).astype(np.float32)
-        frame = np.kron(base, np.ones((8, 8, 1), np.float32))[:H, :W] + rs.randint(-9, 10, (H, W, 3))
-        frame = np.clip(frame, 0, 255).astype(np.uint8)
-        host = u.img_preprocess(frame, None, single_img_input=True)
+    for H, W in ((1080, 1920), (480, 640), (700, 301), (512, 512), (333, 333), (64, 48)):
+        frame = _blocky(rs, H, W)
+        want_img, want_off = opre.img_preprocess(frame)
         dev_img, dev_off = ops.preprocess(torch.from_numpy(frame)[None].cuda())
-        diff = (dev_img.cpu().int() - host['image'].int()).abs()
-        assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 2e-3, (H, W, diff.max().item())
-        assert torch.equal(dev_off, host['offsets'])
+        assert torch.equal(dev_img[0].cpu(), torch.from_numpy(want_img)), (H, W)
+        assert torch.equal(dev_off[0], torch.from_numpy(want_off)), (H, W)
+    noise = rs.randint(0, 256, (2, 720, 1280, 3)).astype(np.uint8)         # batched call, worst-case content
+    dev_img, _ = ops.preprocess(torch.from_numpy(noise).cuda())
+    for i in range(2):
+        assert torch.equal(dev_img[i].cpu(), torch.from_numpy(opre.img_preprocess(noise[i])[0]))
+
+
+def test_magic_jpg_end_to_end_matches_reference(synth_sd, mano_tables):
+    """BASELINE.json configs[0]: the reference's demo image through acr.main.ACR - JPEG decoded with PIL, device
+    pre-processing, backbone, heads, decode, MANO - against what the real reference's img_preprocess + ACR +
+    MANOWrapper produced from the same pixels (tests/golden/magic_e2e.npz)."""
+    import os
+    from PIL import Image
+    from conftest import GOLDEN
+    g = golden('magic_e2e.npz')
+    bgr = np.ascontiguousarray(np.asarray(Image.open(os.path.join(GOLDEN, 'magic.jpg')).convert('RGB'))[:, :, ::-1])
+    u = pkg('acr.utils')
+    meta = u.img_preprocess(bgr, 'demo/magic.jpg', single_img_input=True)
+    assert meta['image'].is_cuda and meta['offsets'].tolist() == g['offsets'].tolist()
+    np.testing.assert_array_equal(meta['image'][0].cpu().numpy()[::4, ::4], g['image_sub'])
+    assert int(meta['image'].long().sum()) == int(g['image_sum'][0])
+    acr = pkg('acr.main').ACR(state_dict=synth_sd, mano_tables=mano_tables)
+    out = acr.single_image_forward(bgr, 'demo/magic.jpg')
+    out, res = acr.process_results(out)
+    np.testing.assert_array_equal(out['detection_flag_cache'].cpu().numpy(), g['detection_flag'].astype(bool))
+    np.testing.assert_array_equal(out['l_centers_pred'].cpu().numpy(), g['l_centers_pred'])
+    np.testing.assert_allclose(out['params_pred'].cpu().numpy(), g['params_pred'], 2e-4, 2e-4)
+    assert np.abs(out['verts'].cpu().numpy() - g['verts']).max() < 1e-4
+    assert np.abs(out['j3d'].cpu().numpy() - g['j3d']).max() < 1e-4
+    np.testing.assert_allclose(out['pj2d_org'].cpu().numpy(), g['pj2d_org'], 1e-3, 0.2)      # pixels of a 1920 frame
+    np.testing.assert_allclose(out['cam_trans'].cpu().numpy(), g['cam_trans'], 5e-3, 5e-3)
+    assert len(res['demo/magic.jpg']) == int(g['detection_flag'].sum())
+
+
+def test_device_smoothing_matches_reference_sequence():
+    """§8f-3: acrmi_smooth (One-Euro state in the context) == the reference's smooth_results over a 14-frame
+    sequence (late-appearing hand, two-frame drop-out, near-pi orientation) - frame by frame as acr/main.py calls
+    it, and as one 14-frame call of a video shard."""
+    L = pkg('_lib')
+    g = golden('smooth_seq.npz')
+    poses, betas, flags = cases.smooth_inputs()
+    T = poses.shape[0]
+    slots = torch.zeros(T, 2, L.SLOT)
+    slots[:, :, L.SLOT_FLAG] = torch.from_numpy(flags.astype(np.float32))
+    slots[:, :, L.SLOT_POSES:L.SLOT_POSES + 48] = torch.from_numpy(poses)
+    slots[:, :, L.SLOT_BETAS:L.SLOT_BETAS + 10] = torch.from_numpy(betas)
+    eng = pkg('engine').Engine(0)
+    eng.set_temporal(False, smooth_coeff=float(g['smooth_coeff']))
+    one = slots.clone().cuda()
+    eng.smooth_reset()
+    for t in range(T):
+        eng.smooth(one[t:t + 1])
+    allatonce = slots.clone().cuda()
+    eng.smooth_reset()
+    eng.smooth(allatonce)
+    torch.cuda.synchronize()
+    assert torch.equal(one, allatonce)
+    got = one.cpu().numpy()
+    assert np.abs(got[:, :, L.SLOT_POSES:L.SLOT_POSES + 48] - g['poses']).max() < 1e-5
+    assert np.abs(got[:, :, L.SLOT_BETAS:L.SLOT_BETAS + 10] - g['betas']).max() < 1e-5
+    untouched = np.ones(L.SLOT, bool)
+    untouched[L.SLOT_POSES:L.SLOT_BETAS + 10] = False
+    np.testing.assert_array_equal(got[:, :, untouched], slots.numpy()[:, :, untouched])
+    eng.close()
+
+
+def test_temporal_optimization_through_acr_main(synth_sd, mano_tables, frames2):
+    """`-t`: acr.main.ACR smooths the decoded poses on the device before MANO (acr/main.py:69-83).  Three calls on
+    alternating frames == the oracle's One-Euro filter run over the un-smoothed per-frame parameters."""
+    from oracle import smooth as osm
+    cfg = pkg('config')
+    base = ['--configs_yml', '/nonexistent.yml']
+    plain = pkg('acr.main').ACR(args_set=cfg.parse_args(base), state_dict=synth_sd, mano_tables=mano_tables)
+    temp = pkg('acr.main').ACR(args_set=cfg.parse_args(base + ['-t', '--smooth_coeff', '3.0']), state_dict=synth_sd,
+                               mano_tables=mano_tables)
+    seq = [frames2[0], frames2[1], frames2[0]]
+    filt = {0: osm.new_filters(3.0), 1: osm.new_filters(3.0)}
+    for t, f in enumerate(seq):
+        bgr = np.ascontiguousarray(f[:, :, ::-1])
+        raw = plain.process_results(plain.single_image_forward(bgr, 'p'))[0]
+        sm = temp.process_results(temp.single_image_forward(bgr, 'p'))[0]
+        for sid in range(2):
+            p, b = osm.smooth_results(filt[sid], raw['params_dict']['poses'][sid].cpu().numpy(),
+                                      raw['params_dict']['betas'][sid].cpu().numpy())
+            assert np.abs(sm['params_dict']['poses'][sid].cpu().numpy() - p).max() < 2e-5, (t, sid)
+            assert np.abs(sm['params_dict']['betas'][sid].cpu().numpy() - b).max() < 2e-5, (t, sid)
+        if t == 0:
+            assert torch.allclose(sm['verts'], raw['verts'], atol=1e-6)         # first sample passes through
+        else:
+            assert (sm['verts'] - raw['verts']).abs().max() > 1e-5              # later ones are filtered
+
+
+def test_options_conf_thresh_and_center_idx(synth_sd, mano_tables, frames2):
+    """centermap_conf_thresh and align_idx / mano_mesh_root_align reach the kernels of BOTH entry points
+    (ACR.forward and the fused forward_batch) instead of being hard-coded."""
+    cfg = pkg('config')
+    base = ['--configs_yml', '/nonexistent.yml']
+    g = golden('net_frame0.npz')
+    l_max = float(g['l_center_map'].max())                   # 0.95: a threshold above it drops the left hand only
+    acr = pkg('acr.main').ACR(args_set=cfg.parse_args(base + ['--centermap_conf_thresh', '%.3f' % (l_max + 0.02)]),
+                              state_dict=synth_sd, mano_tables=mano_tables, max_batch=2)
+    res = acr(np.ascontiguousarray(frames2[0][:, :, ::-1]), 'a')['a']
+    assert [int(h['hand_type']) for h in res] == [1]
+    batch = acr.forward_batch(torch.from_numpy(frames2), ['a', 'b'])
+    assert [int(h['hand_type']) for h in batch['a']] == [1] and [int(h['hand_type']) for h in batch['b']] == [1]
+    # root alignment: joint 0 instead of 9, and none at all
+    for extra, idx in ((['--align_idx', '0'], 0), (['--mano_mesh_root_align', 'false'], None)):
+        acr = pkg('acr.main').ACR(args_set=cfg.parse_args(base + extra), state_dict=synth_sd, mano_tables=mano_tables,
+                                  max_batch=2)
+        one = acr(np.ascontiguousarray(frames2[0][:, :, ::-1]), 'a')['a']
+        fused = acr.forward_batch(torch.from_numpy(frames2[:1]), ['a'], point_heads=False)['a']
+        for h1, h2 in zip(one, fused):
+            assert np.abs(h1['j3d'].astype(np.float32) - h2['j3d'].astype(np.float32)).max() < 2e-3
+            if idx is not None:
+                assert np.abs(h1['j3d'][idx].astype(np.float32)).max() < 1e-6      # the alignment joint sits at the origin
+            else:
+                assert np.abs(h1['j3d'][9].astype(np.float32)).max() > 1e-3
+    eng = acr.model.engine()
+    with pytest.raises(ValueError):
+        eng.set_center_idx(21)
+
+
+def test_checkpoint_reload_keeps_mano_and_wrapper_working(synth_sd, mano_tables, frames2):
+    """ACR_v1.load_state_dict rebuilds the engine; the new context adopts the MANO tables and options and
+    MANOWrapper follows the model's current engine instead of the retired one."""
+    g = golden('e2e_batch1.npz')
+    acr = pkg('acr.main').ACR(state_dict=pkg('synth').make_state_dict(seed=3), mano_tables=mano_tables)
+    first = acr.model.engine()
+    acr.model.load_state_dict({'module.' + k: v for k, v in synth_sd.items()})
+    res = acr(np.ascontiguousarray(frames2[0][:, :, ::-1]), 'a')['a']
+    assert acr.model.engine() is not first and acr.mano_regression.engine() is acr.model.engine()
+    for i, h in enumerate(res):
+        assert np.abs(h['verts'].astype(np.float32) - g['f0_verts'][i]).max() < 2e-3
+    fused = acr.forward_batch(torch.from_numpy(frames2[:1]), ['a'])['a']          # needs both sides' tables in the ctx
+    assert 'cam_trans' in fused[0] and fused[0]['cam_trans'].dtype == np.float16
+    assert np.abs(fused[0]['cam_trans'].astype(np.float32) - res[0]['cam_trans'].astype(np.float32)).max() < 2e-2
+
+
+def test_allgather_through_the_c_abi_world_size_1():
+    """acrmi_comm_unique_id / acrmi_comm_init / acrmi_allgather (RCCL resolved at run time) with one
+    rank: the gather is the identity, on the caller's stream and on a side stream."""
+    import ctypes as C
+    L = pkg('_lib')
+    eng = pkg('engine').Engine(0)
+    uid = (C.c_char * 128)()
+    L.check(L.lib().acrmi_comm_unique_id(uid))
+    assert any(bytes(uid))
+    send = torch.arange(40000, dtype=torch.float32, device='cuda') * 0.5
+    recv = torch.zeros_like(send)
+    with pytest.raises(L.AcrmiError):
+        eng.comm_ranks = 1
+        eng.allgather(send, recv)                               # no communicator yet: ACRMI_ESTATE, not a crash
+    eng.comm_init(1, 0, bytes(uid))
+    eng.allgather(send, recv)
+    side = torch.cuda.Stream()
+    recv2 = torch.zeros_like(send)
+    side.wait_stream(torch.cuda.current_stream())
+    eng.allgather(send, recv2, stream=side)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send) and torch.equal(recv2, send)
+    eng.close()
+
+
+def test_sharded_runner_over_rccl_world_size_1(synth_sd, mano_tables, frames2):
+    """parallel.ShardedRunner on the GPU with both transports (torch.distributed nccl = RCCL, and acrmi_allgather)
+    at world size 1: pipelined submit/collect returns exactly Engine.forward's results."""
+    import os
+    import torch.distributed as dist
+    parallel = pkg('parallel')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        eng = pkg('engine').Engine(0)
+        eng.load_state_dict(synth_sd, max_batch=2)
+        t = {k: dict(v) for k, v in mano_tables.items()}
+        t['left']['shapedirs'] = t['left']['shapedirs'].copy()
+        t['left']['shapedirs'][:, 0, :] *= -1
+        eng.load_mano(t)
+        x = torch.from_numpy(frames2).cuda()
+        want = {k: v.clone() for k, v in eng.forward(x).items()}
+        for transport in ('torch', 'c'):
+            runner = parallel.ShardedRunner(lambda f, views: eng.forward(f, out=views), eng.device, engine=eng,
+                                            transport=transport)
+            t0 = runner.submit(x)
+            t1 = runner.submit(x.flip(0).contiguous())
+            r0, r1 = runner.collect(t0), runner.collect(t1)
+            torch.cuda.synchronize()
+            for k in ('slots', 'verts', 'joints'):
+                assert torch.equal(r0[k], want[k]), (transport, k)
+                assert torch.equal(r1[k], want[k].flip(0)), (transport, k)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_malformed_programs_are_rejected(synth_sd):
+    """acrmi_set_program validates buffer ids (incl. FUSESUM terms and the head layout), weight offsets
+    and channel slices - ACRMI_EINVAL instead of a device fault."""
+    import ctypes as C
+    L, packer = pkg('_lib'), pkg('packer')
+    prog = packer.lower(synth_sd)
+    eng = pkg('engine').Engine(0)
+    blob = prog['blob']
+    L.check(L.lib().acrmi_load_weights(eng.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), eng.ctx)
+    bufs = (L.BufferDesc * len(prog['bufs']))(*[L.BufferDesc(*b) for b in prog['bufs']])
+
+    def try_program(mutate):
+        ops = (L.Op * len(prog['ops']))(*[L.Op.from_buffer_copy(bytes(o)) for o in prog['ops']])
+        heads = L.HeadLayout.from_buffer_copy(bytes(prog['heads']))
+        mutate(ops, heads)
+        return L.lib().acrmi_set_program(eng.ctx, bufs, len(bufs), ops, len(ops), C.byref(heads), 1)
+    fuse = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_FUSESUM)
+    conv = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_CONV and o.ksize == 3)
+
+    def set_(i, field, val):
+        return lambda ops, heads: setattr(ops[i], field, val)
+
+    def term(ops, heads):
+        ops[fuse].term_buf[1] = len(prog['bufs']) + 3
+    cases_ = [term, set_(conv, 'w_off', blob.size - 8), set_(conv, 'in_buf', -1), set_(conv, 'out_coff', 4096),
+              set_(conv, 'cin', 4096), set_(conv, 'b_off', -5), set_(conv, 'mode', 7), set_(conv, 'ksize', 5),
+              lambda ops, heads: heads.center_buf.__setitem__(0, 999),
+              lambda ops, heads: heads.params_buf.__setitem__(1, heads.center_buf[0])]
+    for m in cases_:
+        assert try_program(m) == L.E_INVAL
+        assert L.lib().acrmi_last_error(eng.ctx)
+    assert try_program(lambda ops, heads: None) == 0           # the untouched program still loads
+    eng.close()
 
 
 def test_raw_1080p_batch_end_to_end(synth_sd, mano_tables):

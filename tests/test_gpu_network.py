@@ -255,6 +255,181 @@ def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
     eng.close()
 
 
+def test_intermediate_backbone_taps_match_reference_golden(synth_sd, frames2):
+    """not only the backbone output but the taps in between - stem, layer1, stage2 and stage3
+    (branch 0) - equal the reference's activations (net_frame0.npz), so a compensating error pair cannot hide."""
+    g = golden('net_frame0.npz')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=1, keep_taps=True)
+    eng.backbone_heads(torch.from_numpy(frames2[:1]).cuda())
+    torch.cuda.synchronize()
+    chans = {'stem': 64, 'layer1': 256, 'stage2': 32, 'stage3': 32}
+    for name, c in chans.items():
+        t = eng.buffer(eng.program['taps'][name], 1, c).cpu().permute(0, 3, 1, 2).contiguous().numpy()
+        sub, sums = cases.sub(t)
+        scale = max(1.0, float(np.abs(g['tap_' + name]).max()))
+        assert np.abs(sub - g['tap_' + name]).max() < 1e-4 * scale, name
+        np.testing.assert_allclose(sums, g['tap_%s_sum' % name], rtol=2e-5)
+    # pinning the taps changes buffer aliasing only: the final maps are bit-identical to the default lowering
+    plain = pkg('engine').Engine(0)
+    plain.load_state_dict(synth_sd, max_batch=1)
+    plain.backbone_heads(torch.from_numpy(frames2[:1]).cuda())
+    for k, v in plain.head_maps(1).items():
+        assert torch.equal(v, eng.head_maps(1)[k]), k
+    eng.close()
+    plain.close()
+
+
+@pytest.mark.parametrize('name', list(cases.STATE_CHECKPOINTS))
+def test_detection_states_through_the_network(name, mano_tables):
+    """left-only / right-only / none / both-with-prior (centres <= 32 px apart) through the WHOLE
+    network against the real reference (e2e_states.npz), the golden frames scattered in a larger batch - batch 64 for
+    the both-hands state, 8 for the others - with the rest of the batch checked against the frame's own batch-1 run."""
+    g = golden('e2e_states.npz')
+    L = pkg('_lib')
+    synth = pkg('synth')
+    B = 64 if name == 'both_near' else 8
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth.make_state_dict(seed=cases.STATE_CHECKPOINTS[name]), max_batch=B)
+    eng.load_mano(_flip_left(mano_tables))
+    gold = synth.make_frames(2, seed=cases.STATE_FRAME_SEED)
+    batch = synth.make_frames(B, seed=77, structured=True)
+    spots = {0: (1, B - 1), 1: (0, B // 2)}
+    for b, pos in spots.items():
+        for p in pos:
+            batch[p] = gold[b]
+    out = eng.forward(torch.from_numpy(batch).cuda())
+    torch.cuda.synchronize()
+    slots = out['slots'].cpu().numpy()
+    for b, pos in spots.items():
+        key = '%s_f%d_' % (name, b)
+        for p in pos:
+            np.testing.assert_array_equal(slots[p, :, L.SLOT_FLAG] > 0.5, g[key + 'detection_flag'].astype(bool))
+            lc, rc = g[key + 'l_centers_pred'][0], g[key + 'r_centers_pred'][0]
+            assert slots[p, 0, L.SLOT_FLATIND] == lc[1] * 64 + lc[0] and slots[p, 1, L.SLOT_FLATIND] == rc[1] * 64 + rc[0]
+            np.testing.assert_allclose(slots[p, :, L.SLOT_PARAMS:L.SLOT_PARAMS + 109], g[key + 'params_pred'], 2e-4, 2e-4)
+            if name != 'none':                   # the reference does not run MANO when nothing is detected
+                assert np.abs(out['verts'][p].cpu().numpy() - g[key + 'verts']).max() < 1e-4
+                assert np.abs(out['joints'][p].cpu().numpy() - g[key + 'j3d']).max() < 1e-4
+    one = eng.forward(torch.from_numpy(batch[3:4]).cuda())        # any other frame: batch-invariant
+    assert torch.equal(one['slots'][0], out['slots'][3]) and torch.equal(one['verts'][0], out['verts'][3])
+    eng.close()
+
+
+def test_config3_1080p_shard_of_32_frames(synth_sd, mano_tables):
+    """BASELINE.json configs[3] per-GPU workload (batch 128 over 4 GPUs = 32 frames per GPU): 32 raw 1080p BGR frames
+    in HBM -> acrmi_preprocess -> acrmi_forward, at fp32 tolerance: the pre-processed frames equal the oracle's
+    (OpenCV restatement) bit for bit on all 32, vertices/joints are within 1e-4 m of the oracle network + MANO on 6
+    of them spread over the batch, and every frame equals its own batch-1 run."""
+    from oracle import preprocess as opre
+    synth = pkg('synth')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=32)
+    eng.load_mano(_flip_left(mano_tables))
+    rs = np.random.RandomState(11)
+    small = synth.make_frames(32, seed=21, size=270)[:, :, :, ::-1]                   # BGR content
+    raw = np.empty((32, 1080, 1920, 3), np.uint8)
+    for i in range(32):
+        up = np.kron(small[i, :, :240], np.ones((4, 8, 1), np.uint8))                   # 1080 x 1920
+        raw[i] = np.clip(up.astype(np.int16) + rs.randint(-6, 7, up.shape), 0, 255).astype(np.uint8)
+    dev_raw = torch.from_numpy(raw).cuda()
+    img, offsets = pkg('ops').preprocess(dev_raw)
+    assert offsets[0].tolist() == [1920, 1920, 0, 0, 0, 0, 420, 0, 420, 0]
+    out = eng.forward(img, offsets=offsets.cuda(), project=True)
+    torch.cuda.synchronize()
+    host_img = img.cpu().numpy()
+    picks = (0, 5, 13, 18, 26, 31)
+    want = {i: opre.img_preprocess(raw[i])[0] for i in range(32)}
+    for i in range(32):
+        np.testing.assert_array_equal(host_img[i], want[i])
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    with torch.no_grad():
+        maps = acr_net.network(synth_sd, torch.from_numpy(np.stack([want[i] for i in picks])))
+    slots = odec.decode(maps)
+    t = _flip_left(mano_tables)
+    L = pkg('_lib')
+    got = out['slots'].cpu().numpy()
+    for k, i in enumerate(picks):
+        np.testing.assert_array_equal(got[i, :, L.SLOT_FLAG] > 0.5, slots['flag'][k])
+        np.testing.assert_array_equal(got[i, :, L.SLOT_FLATIND], slots['flat_ind'][k].astype(np.float32))
+        for h, side in ((0, 'left'), (1, 'right')):
+            v, j, _ = omano.mano_forward(t[side], side, slots['poses'][k, h:h + 1], slots['betas'][k, h:h + 1])
+            assert np.abs(out['verts'][i, h].cpu().numpy() - v[0]).max() < 1e-4
+            assert np.abs(out['joints'][i, h].cpu().numpy() - j[0]).max() < 1e-4
+            _, pj, org = omano.project(v, j, slots['cam'][k, h:h + 1], np.array([[1920, 1920, 0, 0, 0, 0, 420, 0, 420, 0]], np.float32))
+            np.testing.assert_allclose(out['pj2d_org'][i, h].cpu().numpy(), org[0], rtol=1e-4, atol=0.1)
+    for i in (1, 17, 30):
+        one = eng.forward(img[i:i + 1].contiguous(), offsets=offsets[i:i + 1].cuda(), project=True)
+        for k in ('slots', 'verts', 'joints', 'pj2d_org'):
+            assert torch.equal(one[k][0], out[k][i]), (i, k)
+    eng.close()
+
+
+def test_parebias_kernel_matches_oracle(synth_sd, hip_maps):
+    """N10 (LocallyConnected2d, acr/model.py:559-569) + the shape Linear + the mix conv's pare columns
+    (acr/model.py:141-164) as a unit: acrmi_parebias on the reference's raw weights and pooled features vs
+    oracle.acr_net.pare_vector, for both sides, real pooled features and random ones."""
+    ops = pkg('ops')
+    torch.manual_seed(5)
+    B = 5
+    wc = torch.randn(B, 256, 32, 1) * 0.7
+    ws = torch.randn(B, 64, 32) * 0.7
+    pooled = torch.cat([wc[..., 0], ws], 1).transpose(1, 2).contiguous()             # [B,32,320]
+    for side, lc, mix, part0 in (('l', 2, 4, 16), ('r', 3, 5, 0)):
+        pare = acr_net.pare_vector(synth_sd, side, wc, ws).double().numpy()          # [B,106]
+        wm = synth_sd['contact_layers.%d.weight' % mix].double().numpy().reshape(109, 218)
+        want = synth_sd['contact_layers.%d.bias' % mix].double().numpy() + pare @ wm[:, 112:].T
+        got = ops.parebias(pooled.cuda(), synth_sd['contact_layers.%d.weight' % lc].numpy().reshape(6, 256, 16),
+                           synth_sd['cam_shape_layers.%d.weight' % lc].numpy(), synth_sd['cam_shape_layers.%d.bias' % lc].numpy(),
+                           wm[:, 112:], synth_sd['contact_layers.%d.bias' % mix].numpy(), part0).cpu().numpy()
+        assert got.shape == (B, 112) and (got[:, 109:] == 0).all()
+        np.testing.assert_allclose(got[:, :109], want, rtol=2e-5, atol=2e-5)
+        # a spatially constant pare vector is what the mix conv sees: LC offsets depend on this side's 16 parts only
+        other = pooled.clone()
+        other[:, (0 if part0 else 16):(16 if part0 else 32)] += 1.0
+        got2 = ops.parebias(other.cuda(), synth_sd['contact_layers.%d.weight' % lc].numpy().reshape(6, 256, 16),
+                            synth_sd['cam_shape_layers.%d.weight' % lc].numpy(), synth_sd['cam_shape_layers.%d.bias' % lc].numpy(),
+                            wm[:, 112:], synth_sd['contact_layers.%d.bias' % mix].numpy(), part0).cpu().numpy()
+        np.testing.assert_array_equal(got, got2)
+    with pytest.raises(ValueError):
+        ops.parebias(pooled[:, :, :100].cuda(), np.zeros((6, 256, 16)), np.zeros((10, 1024)), np.zeros(10), np.zeros((109, 106)),
+                     np.zeros(109), 0)
+
+
+def test_decision_margins_at_batch_64(synth_sd, hip_maps, oracle_maps):
+    """VERDICT r1 1(d) / SURVEY.md 7: how close the discrete decisions (NMS equality, arg-max, > 0.35) come to
+    flipping.  Over 64 structured frames x 2 sides: the margin between the best and the second-best NMS survivor
+    and between the best score and the threshold, against the measured GPU-vs-oracle error of the center maps.
+    The histogram goes to gpurun_out/r02_tie_rate.json (DESIGN.md quotes it)."""
+    import json
+    import os
+    import torch.nn.functional as F
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=64)
+    x = torch.from_numpy(pkg('synth').make_frames(64, seed=123, structured=True)).cuda()
+    B = eng.backbone_heads(x)
+    maps = eng.head_maps(B)
+    err = max((hip_maps[k] - oracle_maps[k]).abs().max().item() for k in ('l_center_map', 'r_center_map'))
+    margins, thr = [], []
+    for k in ('l_center_map', 'r_center_map'):
+        c = maps[k].float()
+        keep = (F.max_pool2d(c, 5, 1, 2) == c).float() * c
+        top = torch.topk(keep.reshape(B, -1), 2, dim=1).values
+        margins += (top[:, 0] - top[:, 1]).cpu().tolist()
+        thr += (top[:, 0] - 0.35).abs().cpu().tolist()
+    edges = [0, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e9]
+    hist = np.histogram(margins, bins=edges)[0].tolist()
+    rep = {'frames': 64, 'decisions': len(margins), 'center_map_max_abs_err_vs_oracle': err,
+           'top2_margin_min': min(margins), 'top2_margin_hist_edges': edges[:-1], 'top2_margin_hist': hist,
+           'threshold_margin_min': min(thr), 'ties_within_10x_err': int(sum(m < 10 * err for m in margins))}
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/r02_tie_rate.json', 'w') as f:
+        json.dump(rep, f, indent=1)
+    assert err < 5e-5
+    assert rep['ties_within_10x_err'] == 0 and min(thr) > 10 * err, rep
+    eng.close()
+
+
 def test_engine_argument_errors(engine):
     with pytest.raises(ValueError):
         engine.forward(torch.zeros(1, 256, 256, 3, dtype=torch.uint8).cuda())

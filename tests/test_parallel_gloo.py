@@ -72,7 +72,21 @@ def _worker(rank, world, port, q):
         got = runner.forward_global(frames)               # strong-scaling entry: shard of the global batch
         lo, hi = parallel.shard_range(len(NAMES), rank, world)
         got2 = runner.forward_local(frames[lo:hi])         # weak-scaling entry gives the same thing
-        q.put((rank, {k: v.numpy() for k, v in got.items()}, all(torch.equal(got[k], got2[k]) for k in got)))
+        # pipelined form: batch k's gather is queued while batch k+1 is computed (double-buffered results)
+        t0 = runner.submit(frames[lo:hi])
+        t1 = runner.submit(frames[lo:hi].flip(0))
+        try:
+            runner.submit(frames[lo:hi])
+            third = False
+        except RuntimeError:
+            third = True                                   # a third outstanding ticket would overwrite batch k
+        r0, r1 = runner.collect(t0), runner.collect(t1)
+        per = hi - lo
+        flipped = torch.cat([got['slots'][r * per:(r + 1) * per].flip(0) for r in range(world)])
+        same = all(torch.equal(got[k], got2[k]) and torch.equal(got[k], r0[k]) for k in got)
+        # (the stand-in's torch-CPU math differs by ~1e-7 with a frame's position in the batch: allclose, not equal)
+        same = same and third and torch.allclose(r1['slots'], flipped, rtol=0, atol=2e-6)
+        q.put((rank, {k: v.numpy() for k, v in got.items()}, same))
     finally:
         dist.destroy_process_group()
 

@@ -4,7 +4,7 @@
 # then copy gpurun_out/<tag>_* into profiles/.  Kernel timing and the PMC passes are separate runs (rocprofv3 --pmc
 # must not be combined with other trace domains on this pool).
 set -u
-TAG=${1:-rXX}
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"

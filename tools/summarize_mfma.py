@@ -1,5 +1,7 @@
 """Per-kernel matrix-pipe occupancy from a rocprofv3 PMC pass (tools/profile_round.sh: SQ_BUSY_CU_CYCLES,
-SQ_VALU_MFMA_BUSY_CYCLES).  usage: summarize_mfma.py <dir with *counter_collection.csv> <out.txt>"""
+SQ_VALU_MFMA_BUSY_CYCLES).  usage: summarize_mfma.py <dir with *counter_collection.csv> <out.txt>
+Also writes <out>.json (per-variant busy fraction + launch-weighted means) for bench.py's roofline.mfma_busy_pmc."""
+import json
 import collections
 import csv
 import glob
@@ -29,6 +31,19 @@ def main():
                 continue
             f.write('%-60s launches=%4d  SQ_BUSY_CU_CYCLES=%.3e  SQ_VALU_MFMA_BUSY_CYCLES=%.3e  mfma_busy/(4*cu_busy)=%.3f\n'
                     % (name, len(launches[name]), busy, mfma, mfma / (4 * busy) if busy else 0.0))
+    variants, tot = {}, collections.defaultdict(lambda: [0.0, 0.0])
+    for name, c in rows:
+        busy, mfma = c.get('SQ_BUSY_CU_CYCLES', 0.0), c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+        if busy < 1e8 or 'conv_' not in name:
+            continue
+        variants[name] = {'launches': len(launches[name]), 'mfma_busy_frac': round(mfma / (4 * busy), 4)}
+        fam = 'conv_wino' if 'wino' in name else 'conv_direct'
+        for k in (fam, 'all_convs'):
+            tot[k][0] += mfma
+            tot[k][1] += 4 * busy
+    with open(os.path.splitext(dst)[0] + '.json', 'w') as f:
+        json.dump({'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), summed over launches',
+                   'cycle_weighted': {k: round(v[0] / v[1], 4) for k, v in tot.items()}, 'variants': variants}, f, indent=1)
 
 
 if __name__ == '__main__':
