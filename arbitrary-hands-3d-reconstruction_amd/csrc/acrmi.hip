@@ -1016,6 +1016,7 @@ int acrmi_allgather(acrmi_ctx* c, void* nccl_comm, const float* send_dev, float*
 int acrmi_tune(int key, int value) {
   if (key == 0) { conv_force_cfg(value); return ACRMI_OK; }
   if (key == 3) { conv_set_phase_delay(value); return ACRMI_OK; }
+  if (key == 4) { conv_set_xcd_swizzle(value); return ACRMI_OK; }   // XCD-banded item order on/off (default on)
   static long long* dbg = nullptr;
   if (key == 1) {   // enable (value != 0) / disable the conv kernel's cycle stamps (workgroup 0, wave 0)
     if (value && !dbg) { if (hipMalloc(&dbg, 128 * sizeof(long long)) != hipSuccess) return ACRMI_EHIP; }

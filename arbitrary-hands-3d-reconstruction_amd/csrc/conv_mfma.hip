@@ -38,6 +38,8 @@ static long long* g_dbg = nullptr;
 void conv_set_debug(long long* dbg) { g_dbg = dbg; }
 static int g_phase_delay = 0;
 void conv_set_phase_delay(int cycles) { g_phase_delay = cycles; }
+static int g_xcd_swizzle = 1;
+void conv_set_xcd_swizzle(int on) { g_xcd_swizzle = on; }
 // per-device state: a process may hold contexts on several GPUs (acr.main.ACR(device=...)); kernel attributes
 // (dynamic LDS size) and the CU count belong to a device, not to the process
 static int g_num_cus_dev[MAX_DEVICES] = {};
@@ -64,6 +66,17 @@ static void set_magics(ConvWork& wk) {
 }
 __device__ __forceinline__ int fdiv(int n, unsigned long long magic) {
   return (int)(((unsigned long long)(unsigned)n * magic) >> 40);
+}
+
+// Workgroup b of a launch lands on XCD b % 8 (observed dispatch order on gfx950; used for speed only, never for
+// correctness).  A persistent workgroup walks items vb, vb + grid, vb + 2*grid, ...; with vb = b the 256 items in
+// flight at any time are dealt round-robin over the XCDs, so the n-blocks of one tile (consecutive items) and the
+// tiles whose halos overlap read the same input rows through eight different L2s (r01: FETCH 1.38x the algorithmic
+// input bytes of the Winograd kernel).  With the swizzle XCD x works on the contiguous band of grid/8 items
+// [k*grid + x*grid/8, ...): neighbours share an L2.
+__device__ __forceinline__ int virtual_block(const ConvArgs& a) {
+  const int b = (int)blockIdx.x, g = (int)gridDim.x;
+  return (a.xcd_swizzle && (g & 7) == 0) ? (b & 7) * (g >> 3) + (b >> 3) : b;
 }
 
 // work item -> coordinates
@@ -128,8 +141,9 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
     unsigned pixok;
     int c;   // first channel of this lane's float4
   };
-  int w = blockIdx.x, c0 = 0;        // chunk being written
-  int wn = blockIdx.x, cn0 = 0;      // chunk being requested
+  const int vb = virtual_block(a);
+  int w = vb, c0 = 0;                // chunk being written
+  int wn = vb, cn0 = 0;              // chunk being requested
   int off[NLD];
   unsigned pixok_n = 0;
   const float* __restrict__ inb = a.in;
@@ -351,7 +365,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_win
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cin_pad = a.cin8 * 8;
   const int nchunks = (cin_pad + CK - 1) / CK;
-  const int my_items = wk.total > (int)blockIdx.x ? (wk.total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int vb = virtual_block(a);
+  const int my_items = wk.total > vb ? (wk.total - 1 - vb) / (int)gridDim.x + 1 : 0;
   const int ktotal = my_items * nchunks;
   // Residual staging: [patch 0][patch 1][res 0][res 1].  With >= 2 Cin chunks per item the loader waves fetch the
   // item's residual tile (NCW waves x 2 outputs x 32 slots x 32 couts, rows XOR-swizzled on the 16-byte column)
@@ -412,7 +427,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_win
   const size_t tap_stride = (size_t)a.cin8 * a.n_tiles * 256;
   const size_t step_stride = (size_t)a.n_tiles * 256;
 
-  int w = blockIdx.x, c0 = 0;
+  int w = vb, c0 = 0;
   const bool stamp = a.dbg && blockIdx.x == 0 && tid == 0;
   int ns_ = 0;
   if (stamp) a.dbg[ns_++] = clock64();
@@ -634,6 +649,8 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   a.dbg = g_dbg;
   a.phase_delay = g_phase_delay;
+  static const char* swz_env = getenv("ACRMI_XCD_SWIZZLE");      // A/B runs: 0 = round-robin item order
+  a.xcd_swizzle = swz_env ? atoi(swz_env) : g_xcd_swizzle;
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.algo == 2) {   // Winograd F(2x2,3x3): 3x3 stride 1 only, weights packed with 16 taps

@@ -23,6 +23,7 @@ struct ConvArgs {
                         // 2 Winograd F(2x2,3x3) (3x3 stride 1, weights packed with 4x4 taps)
   long long* dbg;       // optional device buffer for cycle stamps (tuning only)
   int phase_delay;      // tuning: cycles the second half of the grid sleeps before starting (0 = off)
+  int xcd_swizzle;      // 1: work items are dealt to the XCDs in contiguous bands (see virtual_block, conv_mfma.hip)
 };
 
 // one-time per-DEVICE kernel setup (dynamic LDS attribute): true the first time `flags` (one static array per kernel
@@ -36,6 +37,7 @@ const char* conv_kernel_name(const ConvArgs& a);
 void conv_force_cfg(int cfg);
 void conv_set_debug(long long* dbg);
 void conv_set_phase_delay(int cycles);
+void conv_set_xcd_swizzle(int on);
 
 hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStream_t s);
 hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,
