@@ -414,8 +414,11 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
           op.groups <= 0 || (op.ksize == 1 && op.stride != 1))
         return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
       const int algo = op.flags & 3;
-      if (algo == 3 || (algo != 0 && !(op.ksize == 3 && op.stride == 1)))
+      if (algo != 0 && !(op.ksize == 3 && op.stride == 1))
         return fail(c, ACRMI_EINVAL, "op %d: algo %d needs a 3x3 stride-1 convolution", i, algo);
+      if (algo == 3 && (op.groups != 1 || op.cin > 32 || op.cout != 32 || op.bias_per_frame || bufs[op.out_buf].h % 8 ||
+                        bufs[op.out_buf].w % 16 || op.out_coff % 4 || op.res_coff % 4))
+        return fail(c, ACRMI_EINVAL, "op %d: algo 3 needs groups 1, Cin <= 32, Cout = 32, a map of 8x16-pixel tiles", i);
       if (op.in_coff + op.groups * op.cin > bufs[op.in_buf].cs || op.out_coff + op.groups * op.cout > bufs[op.out_buf].cs ||
           (op.res_buf >= 0 && op.res_coff + op.groups * op.cout > bufs[op.res_buf].cs) || (op.groups > 1 && op.cin % 4))
         return fail(c, ACRMI_EINVAL, "op %d: channel slice outside its buffer's channel stride", i);
@@ -425,8 +428,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
           (op.res_buf >= 0 && (bufs[op.res_buf].h != ho || bufs[op.res_buf].w != wo)))
         return fail(c, ACRMI_EINVAL, "op %d: output/residual buffer geometry does not match the convolution", i);
       const long long n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
-      const long long taps = algo == 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize);
-      const long long wn = (long long)op.groups * taps * ((op.cin + 7) / 8) * n_tiles * 256;
+      const long long taps = algo >= 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize);
+      const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ((op.cin + 7) / 8) * n_tiles * 256;
       if (!w_ok(op.w_off, wn)) return fail(c, ACRMI_EINVAL, "op %d: packed weights outside the blob", i);
       if (op.bias_per_frame) {
         if (!buf_ok(op.aux_buf) || bufs[op.aux_buf].cs < op.groups * op.cout)
@@ -820,8 +823,11 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  void* stream) {
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0)
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
-  if (algo != 0 && !((algo == 1 || algo == 2) && ksize == 3 && stride == 1))
+  if (algo != 0 && !((algo >= 1 && algo <= 3) && ksize == 3 && stride == 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-1 convolution", algo);
+  if (algo == 3 && (groups != 1 || cin > 32 || cout != 32 || bias_frame_stride != 0 || H % 8 || W % 16 || out_cs % 4 ||
+                    out_coff % 4 || (res && (res_cs % 4 || res_coff % 4))))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 3 needs groups 1, Cin <= 32, Cout = 32, H %% 8 == 0, W %% 16 == 0");
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))

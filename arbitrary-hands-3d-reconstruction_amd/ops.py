@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .packer import pack_conv, n_tiles_for, winograd_weights, winograd2d_weights
+from .packer import pack_conv, pack_wino3, n_tiles_for, winograd_weights, winograd2d_weights
 
 
 def _p(t):
@@ -42,17 +42,22 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     cout = cout_t // groups
     b = np.zeros(cout_t, np.float32) if bias is None else (
         bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
-    if algo in ('winograd', 'winograd2d'):
+    if algo in ('winograd', 'winograd2d', 'winograd2d_lds'):
         if k != 3 or stride != 1:
             raise ValueError('winograd needs a 3x3 stride-1 convolution')
         tr = winograd_weights if algo == 'winograd' else winograd2d_weights
     elif algo == 'direct':
         tr = lambda t: t
     else:
-        raise ValueError('algo must be "direct", "winograd" or "winograd2d"')
-    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2}[algo]
-    packed = [pack_conv(tr(w[g * cout:(g + 1) * cout].astype(np.float64)), b[g * cout:(g + 1) * cout])
-              for g in range(groups)]
+        raise ValueError('algo must be "direct", "winograd", "winograd2d" or "winograd2d_lds"')
+    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2, 'winograd2d_lds': 3}[algo]
+    if algo_id == 3:
+        if groups != 1 or cout != 32 or cin_g > 32:
+            raise ValueError('winograd2d_lds needs groups = 1, Cout = 32, Cin <= 32')
+        packed = [pack_wino3(w.astype(np.float64), b)]
+    else:
+        packed = [pack_conv(tr(w[g * cout:(g + 1) * cout].astype(np.float64)), b[g * cout:(g + 1) * cout])
+                  for g in range(groups)]
     wp = torch.from_numpy(np.concatenate([p[0] for p in packed])).to(x.device)
     bp = torch.from_numpy(np.concatenate([p[1] for p in packed])).to(x.device)
     B, H, W, cs = x.shape

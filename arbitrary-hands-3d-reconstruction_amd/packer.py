@@ -74,6 +74,21 @@ def pack_conv(w, b):
     return np.ascontiguousarray(wp).reshape(-1), bp
 
 
+def pack_wino3(w, b):
+    """3x3 filters [32, Cin <= 32, 3, 3] -> the LDS-resident layout of conv_wino3_kernel: F(2x2,3x3) taps U = G g G^T
+    as [pos = py*4+px][step s][cout half][lane 64][e 4] with cout = 16*half + (lane & 15),
+    cin = 16*s + 4*(lane >> 4) + e (the A fragments of v_mfma_f32_16x16x4_f32), zero padded to 32x32: 64 KiB."""
+    cout, cin = w.shape[:2]
+    assert w.shape[2:] == (3, 3) and cout == 32 and cin <= 32
+    u = np.zeros((32, 32, 4, 4))
+    u[:cout, :cin] = winograd2d_weights(w)
+    u = u.reshape(2, 16, 2, 4, 4, 4, 4)                   # [half, j, s, kq, e, py, px]
+    u = u.transpose(5, 6, 2, 0, 3, 1, 4)                   # [py, px, s, half, kq, j, e]
+    bp = np.zeros(32, np.float32)
+    bp[:cout] = b
+    return np.ascontiguousarray(u, np.float32).reshape(-1), bp
+
+
 WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
 
 
@@ -95,10 +110,18 @@ def use_winograd(k, stride):
     return k == 3 and stride == 1
 
 
-def conv_algo(k, stride, cin, cout):
-    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3)."""
+# ... and, for Cin <= 32 / Cout = 32 layers on tile-aligned maps, on the kernel that keeps the layer's taps in LDS and a
+# wave's 16 positions in registers (conv_wino3.inc).
+WINOGRAD_LDS = True
+
+
+def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False):
+    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps."""
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
+    if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
+            and not per_frame_bias):
+        return 3
     return 2 if WINOGRAD_2D else 1
 
 
@@ -216,9 +239,12 @@ class Program(object):
             wb_list, cout = [(wp, bp)], 32
         if out is None:
             out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
-        algo = conv_algo(k, stride, cin, cout)
-        tr = (lambda t: t, winograd_weights, winograd2d_weights)[algo]
-        packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
+        algo = conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None)
+        if algo == 3:
+            packed = [pack_wino3(w, b) for (w, b) in wb_list]
+        else:
+            tr = (lambda t: t, winograd_weights, winograd2d_weights)[algo]
+            packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
         w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
         flops = 2.0 * ho * wo * flop_cout * cin_w * k * k * len(wb_list)     # algorithmic (direct-conv) FLOPs
@@ -226,7 +252,7 @@ class Program(object):
                  in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
                  relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=algo,
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
-        self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3')[algo]
+        self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds')[algo]
         return out
 
     def conv_bn(self, src, conv, bn, k, stride, relu, **kw):

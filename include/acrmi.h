@@ -177,7 +177,9 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
 /* Stand-alone operators (same kernels the program uses; for parity tests and embedding).
  * w_packed/bias come from the Python packer (pack_conv).  algo: 0 = direct convolution;
  * 1 = Winograd F(2,3) along x (3x3 stride 1 only; w_packed = pack_conv(winograd_weights(w)));
- * 2 = Winograd F(2x2,3x3) (3x3 stride 1 only; w_packed = pack_conv(winograd2d_weights(w))). */
+ * 2 = Winograd F(2x2,3x3) (3x3 stride 1 only; w_packed = pack_conv(winograd2d_weights(w)));
+ * 3 = Winograd F(2x2,3x3) with the layer's taps resident in LDS (groups 1, Cin <= 32, Cout = 32, H % 8 == 0,
+ *     W % 16 == 0; w_packed = pack_wino3(w), 64 KiB). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,

@@ -136,6 +136,64 @@ def test_conv2d_winograd2d_matches_torch(ops, case):
         assert out[..., cout:].abs().max().item() == 0.0
 
 
+WINO3_CASES = [
+    # B, Cin, H, W, relu, residual
+    (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)
+    (1, 32, 8, 16, False, False),        # a single 8x16 tile
+    (3, 32, 24, 48, True, False),        # 27 tiles: several items per workgroup only with a tiny grid (see cfg loop)
+    (2, 16, 16, 16, True, True),         # Cin = 16: the second 16-channel step multiplies zero-padded taps
+    (1, 20, 32, 32, False, True),        # ragged Cin inside the second step
+    (1, 3, 16, 16, True, False),         # Cin = 3
+    (4, 32, 64, 64, True, True),         # 128 / 64 items
+]
+
+
+@pytest.mark.parametrize('case', WINO3_CASES, ids=lambda c: 'wino3_B%d_%dto32_%dx%d' % c[:4])
+@pytest.mark.parametrize('cfg', [831, 832], ids=['tile8x16_4waves', 'tile16x16_8waves'])
+def test_conv2d_winograd_lds_matches_torch(ops, case, cfg):
+    """conv_wino3_kernel (F(2x2,3x3), taps resident in LDS, 16 positions per wave on v_mfma_f32_16x16x4_f32) vs an
+    fp64 direct convolution, in both workgroup shapes; input / residual / output in channel slices of wider buffers."""
+    B, cin, H, W, relu, use_res = case
+    if cfg == 832 and H % 16:
+        pytest.skip('16x16 tiles need H % 16 == 0')
+    L = pkg('_lib').lib()
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 3)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(32, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(32, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, 40), 3.0, device='cuda')                 # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    dst = torch.full((B, H, W, 48), 7.0, device='cuda')                 # output into channels 8..39
+    L.acrmi_tune(0, cfg)
+    try:
+        ops.conv2d(xin, w, b, relu=relu, cin=cin, in_coff=4, algo='winograd2d_lds', out=dst, out_coff=8,
+                   residual=None if res is None else ops.to_nhwc(res))
+        torch.cuda.synchronize()
+    finally:
+        L.acrmi_tune(0, -1)
+    got = dst[..., 8:40].permute(0, 3, 1, 2).cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err < 5e-5, err          # Winograd F(2x2,3x3) in fp32: ~4x the direct kernel's round-off
+    assert (dst[..., :8] == 7).all() and (dst[..., 40:] == 7).all()     # neighbour channels untouched
+
+
+def test_conv2d_winograd_lds_rejects_what_it_cannot_do(ops):
+    x = torch.zeros(1, 16, 32, 32, device='cuda')
+    for kw in (dict(weight=torch.zeros(64, 32, 3, 3)), dict(weight=torch.zeros(32, 32, 3, 3), groups=1, stride=2),
+               dict(weight=torch.zeros(32, 16, 3, 3), groups=2)):
+        with pytest.raises(ValueError):
+            ops.conv2d(x, algo='winograd2d_lds', **kw)
+    with pytest.raises(ValueError):                                      # 12 rows: not a whole number of 8-row tiles
+        ops.conv2d(torch.zeros(1, 12, 32, 32, device='cuda'), torch.zeros(32, 32, 3, 3), algo='winograd2d_lds')
+
+
 def test_conv2d_channel_slices_and_frame_bias(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 109, 16, 16, generator=g)
