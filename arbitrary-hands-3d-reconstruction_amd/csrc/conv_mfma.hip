@@ -119,7 +119,7 @@ struct NoHook {
 // PREP_SLACK: compute the next item's geometry in the slack before the barrier (direct kernels: their compute waves
 // reach the barrier late) instead of right before its first request (Winograd kernel: there the loader is what the
 // barrier waits for, and anything ahead of it delays every wave).
-template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook, bool PREP_SLACK = true>
+template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook, bool PREP_SLACK = true, int PRIO = 3>
 __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk, float* lds, int ltid, int ktotal,
                                           int cin_pad, Hook hook = Hook()) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4, PAD = KS / 2;
@@ -130,7 +130,9 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   static_assert(NLT % (CK / 4) == 0 && NLD <= 32, "loader geometry");
   // loader waves are the younger waves on their SIMD: without priority their VMEM issue trails the
   // MFMA stream of the compute wave they share the SIMD with and the patch arrives late
-  __builtin_amdgcn_s_setprio(3);
+  // (conv_wino3_kernel's loader has a whole item of slack and runs at priority 0: there the MFMA wave sharing the
+  // SIMD should never lose an issue slot to it)
+  __builtin_amdgcn_s_setprio(PRIO);
   // Per-item geometry (pixel offsets, halo validity) is computed once per work item; per chunk only the channel
   // offset changes, so a chunk costs the loader NLD loads + NLD LDS writes and little VALU.
   // The loads run one chunk ahead of the LDS writes, in two statically named register sets: the requests of chunk

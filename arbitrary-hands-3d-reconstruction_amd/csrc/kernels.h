@@ -24,6 +24,7 @@ struct ConvArgs {
   long long* dbg;       // optional device buffer for cycle stamps (tuning only)
   int phase_delay;      // tuning: cycles the second half of the grid sleeps before starting (0 = off)
   int xcd_swizzle;      // 1: work items are dealt to the XCDs in contiguous bands (see virtual_block, conv_mfma.hip)
+  const float* zeros;   // >= 16 bytes of device zeros (source of halo / pad-channel lanes of conv_wino3's LDS-DMA loader)
 };
 
 // one-time per-DEVICE kernel setup (dynamic LDS attribute): true the first time `flags` (one static array per kernel
