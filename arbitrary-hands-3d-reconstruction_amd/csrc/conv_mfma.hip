@@ -132,7 +132,8 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
   // MFMA stream of the compute wave they share the SIMD with and the patch arrives late
   // (conv_wino3_kernel's loader has a whole item of slack and runs at priority 0: there the MFMA wave sharing the
   // SIMD should never lose an issue slot to it)
-  __builtin_amdgcn_s_setprio(PRIO);
+  if (a.phase_delay == 9) __builtin_amdgcn_s_setprio(0);   // tuning (conv_bench --phase 9): loader at priority 0
+  else __builtin_amdgcn_s_setprio(PRIO);
   // Per-item geometry (pixel offsets, halo validity) is computed once per work item; per chunk only the channel
   // offset changes, so a chunk costs the loader NLD loads + NLD LDS writes and little VALU.
   // The loads run one chunk ahead of the LDS writes, in two statically named register sets: the requests of chunk
@@ -258,6 +259,91 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
     }
   }
   __syncthreads();   // matches the compute waves' final barrier
+}
+
+// ------------------------------------------------------------------------------------------------
+// loader waves with LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without a register stop-over), same patch layout
+// and the same barrier protocol as ws_loader.
+// The register-staged ws_loader costs its SIMD ~NLD loads + NLD ds_write_b128 + ~10 address VALU per load and item,
+// and the MFMA wave sharing the SIMD pays for every one of those issue slots (conv_wino3 stamps: 3.2k-cycle steps
+// with the loader at priority 1-3, 2.9k at priority 0 - where the patch then arrives 1.8k cycles late).  Here a chunk
+// costs a loader wave ceil(PH*PW*(CK/4+1) / (64*NLW)) DMA instructions and, for interior tiles and full chunks, one
+// address add each:
+//  * a DMA instruction writes 64 lanes x 16 bytes to CONSECUTIVE LDS addresses, so the patch [pixel][CK+4 floats] is
+//    treated as a stream of 16-byte slots, CK/4 + 1 per pixel (the pad slot is never fetched - and never read);
+//  * slot -> (patch row, patch column, channel quad) never changes: each lane keeps its tile-relative source offset;
+//    per chunk only a uniform base pointer is new.  On border tiles (halo or ragged tile outside the image) and in a
+//    ragged last chunk (channels >= Cin) the affected lanes fetch the 16-byte zero buffer instead.
+// Needs Cin % 4 == 0 (a channel quad is wholly inside Cin or wholly zero).  One chunk is in flight at a time (two LDS
+// buffers): enough for the MFMA-bound layers, the HBM-bound 1x1 layers keep the run-ahead register loader.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int S, int TH, int TW, int CK, int NLW>
+__device__ __forceinline__ void dma_loader(const ConvArgs& a, const ConvWork& wk, float* lds, int ltid, int my_items,
+                                           int nchunks, int vb) {
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4, PAD = KS / 2, BUF = PH * PW * CP;
+  constexpr int SPP = CK / 4 + 1;                   // 16-byte slots per pixel
+  constexpr int NSLOT = PH * PW * SPP, NI = (NSLOT + NLW * 64 - 1) / (NLW * 64);
+  const int lane = ltid & 63;
+  const int lw = __builtin_amdgcn_readfirstlane(ltid >> 6);
+  // A loader wave's VALU instructions only issue in the gaps of the MFMA stream it shares a SIMD with, so the per-slot
+  // work is kept to: nothing but an address add (interior tile, full chunk), + one AND / compare / select against a
+  // precomputed halo mask (border tile of an exactly tiled map), or the general bounds test (ragged tiles / chunks).
+  int off[NI];          // source offset (floats) relative to the patch origin pixel, first channel of the chunk
+  int halo[NI];         // bit 0/1/2/3: slot lies in the top/bottom/left/right PAD ring of the patch; bits 8.. = pyx below
+  bool live[NI];        // slot is fetched at all (inside the patch, not the pad slot)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = (i * NLW + lw) * 64 + lane;
+    const int pix = f / SPP, c4 = f - pix * SPP;
+    const int py = pix / PW, px = pix - py * PW;
+    off[i] = (py * a.W + px) * a.in_cs + 4 * c4;
+    halo[i] = (py < PAD ? 1 : 0) | (py >= PH - PAD ? 2 : 0) | (px < PAD ? 4 : 0) | (px >= PW - PAD ? 8 : 0) |
+              (c4 << 8) | (px << 16) | (py << 24);
+    live[i] = f < NSLOT && c4 < SPP - 1;
+  }
+  // the map is tiled exactly and the patches of its outermost tiles overhang by at most the PAD ring
+  const bool ring_ok = a.Ho % TH == 0 && a.Wo % TW == 0 && (a.Ho - 1) * S - PAD + KS - a.H <= PAD &&
+                       (a.Wo - 1) * S - PAD + KS - a.W <= PAD;
+  const unsigned lds0 = (unsigned)(size_t)lds;      // LDS byte address of patch buffer 0
+  auto dma = [&](const float* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  int w = vb, k = 0;
+  for (int item = 0; item < my_items; ++item, w += (int)gridDim.x) {
+    const ItemPos ip = item_pos(wk, w);
+    const int iy0 = ip.ty * TH * S - PAD, ix0 = ip.tx * TW * S - PAD;      // image coordinates of the patch origin
+    const int edge = (iy0 < 0 ? 1 : 0) | (iy0 + PH > a.H ? 2 : 0) | (ix0 < 0 ? 4 : 0) | (ix0 + PW > a.W ? 8 : 0);
+    // (the origin may lie outside the tensor: only lanes that pass the halo / bounds test use it)
+    const float* origin = a.in + (((long long)ip.b * a.H + iy0) * a.W + ix0) * (long long)a.in_cs + a.in_coff + ip.g * a.Cin;
+    for (int c = 0; c < nchunks; ++c, ++k) {
+      const int c0 = c * CK;
+      const int nq = (a.Cin - c0 < CK ? a.Cin - c0 : CK) / 4;              // channel quads of this chunk inside Cin
+      const float* base = origin + c0;
+      const unsigned dst0 = lds0 + (unsigned)((k & 1) * BUF * 4);
+      if (edge == 0 && nq == CK / 4) {                  // uniform: interior tile, full chunk
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (live[i]) dma(base + off[i], dst0 + (unsigned)((i * NLW + lw) * 1024));   // lane l lands at dst + 16 l
+      } else if (ring_ok && nq == CK / 4) {             // border tile: the halo ring outside the image fetches zeros
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (live[i]) dma((halo[i] & edge) ? a.zeros : base + off[i], dst0 + (unsigned)((i * NLW + lw) * 1024));
+      } else {                                           // ragged tile and / or ragged chunk
+        const int ylo = iy0 < 0 ? -iy0 : 0, yhi = a.H - 1 - iy0, xlo = ix0 < 0 ? -ix0 : 0, xhi = a.W - 1 - ix0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int py = halo[i] >> 24, px = (halo[i] >> 16) & 255, c4 = (halo[i] >> 8) & 255;
+          const bool in = py >= ylo && py <= yhi && px >= xlo && px <= xhi && c4 < nq;
+          if (live[i]) dma(in ? base + off[i] : a.zeros, dst0 + (unsigned)((i * NLW + lw) * 1024));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (asm loads are not in hipcc's wait bookkeeping)
+      __syncthreads();   // barrier k: chunk k is in buffer k & 1; the compute waves left buffer (k+1) & 1 at their barrier k
+    }
+  }
+  __syncthreads();       // matches the compute waves' final barrier
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -654,6 +740,16 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   a.phase_delay = g_phase_delay;
   static const char* swz_env = getenv("ACRMI_XCD_SWIZZLE");      // A/B runs: 0 = round-robin item order
   a.xcd_swizzle = swz_env ? atoi(swz_env) : g_xcd_swizzle;
+  {   // halo / pad-channel lanes of the LDS-DMA loaders read zeros from here (one small allocation per device)
+    static float* zeros[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!zeros[dev]) {
+      hipError_t e = hipMalloc(&zeros[dev], 256);
+      if (e != hipSuccess) return e;
+      if ((e = hipMemset(zeros[dev], 0, 256)) != hipSuccess) return e;
+    }
+    a.zeros = zeros[dev];
+  }
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.algo == 3) return launch_wino3(a, s);   // F(2x2,3x3), Cin <= 32, Cout = 32: weights packed for LDS residency
