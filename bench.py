@@ -146,6 +146,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='frames per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 / batch-8 latency measurement (profiling runs)')
     ap.add_argument('--no-point-heads', action='store_true', help='skip the separately reported point-heads variant')
     ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default)')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
@@ -278,7 +279,7 @@ def main():
                'roofline': roofline}
         if world == 1 and not args.no_point_heads:
             out['point_heads'] = point_heads_rate(eng, frames, views, args.steps, args.warmup)
-        if world == 1:
+        if world == 1 and not args.no_latency:
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, tables)

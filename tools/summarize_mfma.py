@@ -24,7 +24,7 @@ def main():
     rows = sorted(acc.items(), key=lambda kv: -kv[1].get('SQ_BUSY_CU_CYCLES', 0.0))
     with open(dst, 'w') as f:
         f.write('rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -- '
-                'python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-point-heads --lanes 1 (B=64), summed per kernel\n')
+                'python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-point-heads --no-latency --lanes 1 (B=64), summed per kernel\n')
         for name, c in rows:
             busy, mfma = c.get('SQ_BUSY_CU_CYCLES', 0.0), c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
             if busy < 1e8:
