@@ -5,9 +5,9 @@
 //                 (8 ds_write_b128)
 //   P2 "memory":  y-fold (12 ds_read_b128 + 16 VALU), bias/residual/ReLU (48 VALU, 4 residual loads), 4 x 16-byte
 //                 stores, next item's first window rows (8 ds_read_b128 + 16 v_pk)
-// separated by workgroup barriers.  MODE 0: 4 waves, P1 | P2 | P1 | P2 (today's kernel).  MODE 1: 8 waves (two per
-// SIMD), set A runs P1 while set B runs P2 and vice versa.  Reported: cycles per item per wave set; MODE 1 processes
-// two items in the time MODE 0 needs for one if the phases overlap perfectly.
+// separated by workgroup barriers.  "solo" kernels: 4 waves (one per SIMD) running P1 / P2 alone (today's kernel is
+// P1 + P2 back to back).  MODE 0: 8 waves (two per SIMD), both sets in phase.  MODE 1: set A runs P1 while set B runs
+// P2 and vice versa.  Reported: cycles per item; two waves per SIMD process two items per round.
 // MODE 2: like MODE 1, but the partner only runs the memory instructions of P2 (no VALU) - separates VALU blocking
 // from LDS/VMEM contention.
 #include <hip/hip_runtime.h>
@@ -238,7 +238,7 @@ int main() {
     hipLaunchKernelGGL((solo<2>), dim3(256), dim3(256), lds, 0, d, t, src, dst, items, 1.f);
     report("P2 alone, 4 waves", 1);
     hipLaunchKernelGGL((pingpong<0, 0>), dim3(256), dim3(512), lds, 0, d, t, src, dst, items, 1.f);
-    report("MODE 0: P1 | P2 sequential (8 waves launched, 4 idle)", 1);
+    report("MODE 0: both sets IN phase (P1|P2 together), per item", 2);
     hipLaunchKernelGGL((pingpong<1, 0>), dim3(256), dim3(512), lds, 0, d, t, src, dst, items, 1.f);
     report("MODE 1: anti-phase sets, per item (2 items per round)", 2);
     hipLaunchKernelGGL((pingpong<1, 1>), dim3(256), dim3(512), lds, 0, d, t, src, dst, items, 1.f);
