@@ -58,9 +58,9 @@ def _cpu_model():
 
 def cpu_baseline(sd, tables):
     """the oracle (CPU restatement of the reference, oracle/; kind "port") on this box's host cores,
-    same synthetic frames, batch 1 and batch 8, 2 warm-ups + median of 5, threads = the best of {32, 64, physical
-    cores} from one probe pass each (all logical cores oversubscribe: 0.79 fps on 128 threads in round 1 vs 1.5 fps
-    on 8 vCPUs in the survey).  Bounded: ~20-40 s of CPU work."""
+    same synthetic frames, batch 1 and batch 8, 2 warm-ups + median of 5, threads = the best of {8, 16, 32, 64,
+    physical cores} from one probe pass each (more threads are SLOWER on the 2 x 64-core box: 1.6 s per batch of 8 at 16
+    threads, 7.9 s at 128).  Bounded: ~20-40 s of CPU work."""
     import statistics
     from oracle import acr_net, decode as odec, mano as omano
     frames = torch.from_numpy(pkg('synth').make_frames(8, seed=3))
@@ -78,7 +78,7 @@ def cpu_baseline(sd, tables):
         run(b)
         return time.perf_counter() - t0
     prev = torch.get_num_threads()
-    cands = sorted({n for n in (32, 64, phys or 0, 16) if n and n <= (logical or n)})
+    cands = sorted({n for n in (8, 16, 32, 64, phys or 0) if n and n <= (logical or n)})
     probe = {}
     for n in cands:
         torch.set_num_threads(n)
@@ -91,13 +91,14 @@ def cpu_baseline(sd, tables):
         timed(b); timed(b)                         # 2 warm-ups
         res[b] = statistics.median(timed(b) for _ in range(5))
     torch.set_num_threads(prev)
-    return {'value': round(8 / res[8], 3), 'unit': 'frames/s', 'cores': best, 'kind': 'port',
+    b1, b8 = 1 / res[1], 8 / res[8]
+    return {'value': round(max(b1, b8), 3), 'unit': 'frames/s', 'cores': best, 'kind': 'port',
             'cpu_model': model, 'physical_cores': phys, 'logical_cores': logical,
             'batch1_fps': round(1 / res[1], 3), 'batch8_fps': round(8 / res[8], 3),
             'thread_probe_s_per_batch8': {str(k): round(v, 3) for k, v in probe.items()},
             'sample': 'oracle/ (torch-CPU fp32 restatement of the reference) on the same synthetic 512x512 frames; batch 1 '
-                      'and batch 8, 2 warm-ups + median of 5 passes each at %d threads (best of %s); value = batch-8 rate'
-                      % (best, sorted(probe))}
+                      'and batch 8, 2 warm-ups + median of 5 passes each at %d threads (best of %s); value = the better of the two '
+                      '(batch %d)' % (best, sorted(probe), 1 if b1 >= b8 else 8)}
 
 
 def latency(eng, frames, views_for, batches=(1, 8), iters=20):
