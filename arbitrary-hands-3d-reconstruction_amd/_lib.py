@@ -40,7 +40,7 @@ class HeadLayout(C.Structure):
 EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy', 'acrmi_load_weights',
            'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
-           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
+           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_attpool_ws_floats', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias']
 
@@ -85,6 +85,8 @@ def lib():
     L.acrmi_fuse_sum.argtypes = [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, f32p, i32,
                                  i32, vp]
     L.acrmi_attpool.argtypes = [f32p, i32, f32p, i32, i32, i32, f32p, f32p, vp]
+    L.acrmi_attpool_ws_floats.argtypes = [i32, i32]
+    L.acrmi_attpool_ws_floats.restype = C.c_size_t
     L.acrmi_profile_ops.argtypes = [vp, u8p, i32, vp, i32, vp]
     L.acrmi_tune.argtypes = [i32, i32]
     L.acrmi_preprocess.argtypes = [u8p, i32, i32, i32, u8p, vp, vp]
@@ -101,7 +103,7 @@ def lib():
     L.acrmi_parebias.argtypes = [f32p, i32, i32, f32p, f32p, f32p, f32p, f32p, i32, f32p, i32, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr'):
+        if name not in ('acrmi_last_error', 'acrmi_destroy', 'acrmi_buffer_ptr', 'acrmi_attpool_ws_floats'):
             fn.restype = C.c_int
     _lib = L
     return L

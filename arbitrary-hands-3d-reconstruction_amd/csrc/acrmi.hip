@@ -232,10 +232,8 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
     case ACRMI_OP_ATTPOOL: {
       const auto& ds = desc(op.in_buf);     // segm logits
       const auto& df = desc(op.res_buf);    // features
-      float* stats = c->att_ws;
-      float* part = c->att_ws + (size_t)c->max_batch * 16 * 32 * 2;
       HIPCHK(c, launch_attpool(ptr(op.in_buf), ds.cs, ptr(op.res_buf) + op.res_coff, df.cs, op.cin, B, df.h, df.w,
-                               stats, part, ptr(op.out_buf), s));
+                               c->att_ws, ptr(op.out_buf), s));
       return ACRMI_OK;
     }
     case ACRMI_OP_PAREBIAS: {
@@ -898,11 +896,12 @@ int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, co
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "fuse_sum: %s", hipGetErrorString(e));
 }
 
+size_t acrmi_attpool_ws_floats(int B, int C) { return B > 0 && C > 0 ? attpool_ws_floats(B, C) : 0; }
+
 int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* ws,
                   float* pooled, void* stream) {
   if (!segm || !feat || !ws || !pooled || B <= 0) return fail(nullptr, ACRMI_EINVAL, "acrmi_attpool: bad arguments");
-  float* part = ws + (size_t)B * 16 * 32 * 2;
-  hipError_t e = launch_attpool(segm, segm_cs, feat, feat_cs, C, B, 128, 128, ws, part, pooled, (hipStream_t)stream);
+  hipError_t e = launch_attpool(segm, segm_cs, feat, feat_cs, C, B, 128, 128, ws, pooled, (hipStream_t)stream);
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "attpool: %s", hipGetErrorString(e));
 }
 

@@ -759,10 +759,17 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     // n-tile per wave and one 32-cout block per work item instead
     // Cout = 33 with more than one Cin chunk: one regular tile + the 33rd channel on 4x4x1 MFMAs (conv_wino2.inc ODD)
     const bool odd33 = a.Cout == 33 && a.groups == 1 && a.cin8 * 8 > 32 && g_force_cfg != 804;
-    const bool nt1 = n32 || a.cin8 * 8 <= 32 || odd33;
+    // small batches: when two-n-tile items would not even fill the CUs once, one n-tile per item gives twice as many
+    // items of half the length (256->256 at 16x16, one frame: 8 items of 85k cycles -> 16 of 45k; conv_bench --cfg 806
+    // keeps two)
+    hipError_t de = ensure_device_info();
+    if (de != hipSuccess) return de;
+    const long items2 = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16) * a.B * ((a.n_tiles + 1) / 2) * a.groups;
+    const bool few = items2 < g_num_cus_dev[current_device()] && g_force_cfg != 806;
+    const bool nt1 = n32 || a.cin8 * 8 <= 32 || odd33 || few;
     // 8 < Cin <= 16 with Cout >= 64: two 8-channel chunks give the two-n-tile kernel the two barriers per item its
     // single-buffered exchange area needs (instead of one n-tile per item and the input transform once per 32 couts)
-    if (!n32 && !odd33 && a.cin8 == 2 && g_force_cfg != 807) return launch_wino2<2, 8, 2>(a, s);
+    if (!n32 && !odd33 && !few && a.cin8 == 2 && g_force_cfg != 807) return launch_wino2<2, 8, 2>(a, s);
     if (g_force_cfg == 801) return nt1 ? launch_wino2<1, 32, 4>(a, s) : launch_wino2<2, 32, 4>(a, s);
     return nt1 ? launch_wino2<1, 32, 2>(a, s) : launch_wino2<2, 32, 2>(a, s);
   }

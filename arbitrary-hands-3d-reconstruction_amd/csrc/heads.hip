@@ -10,12 +10,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // Part attention (acr/model.py:103-113,126-136): pooled[b][p][c] = sum_pix softmax_pix(logit[b][p])[pix] * feat[b][pix][c]
 // logits = segm channels 1..32 at even pixels (nearest /2 of the 256x256 map, acr/model.py:126-128).
-// Pass 1: per (frame, 1/16 of the pixels) online max / sum-exp per part, lanes <-> parts (128 B coalesced rows).
-// Pass 2: per (frame, 1/8 of the pixels): GEMM [32 parts x K pixels] x [K x C] on v_mfma_f32_32x32x2_f32,
-//         A = exp(logit - max) computed on the fly, B = feature rows straight from HBM (read exactly once).
-// Pass 3: deterministic reduction of the partial tiles, scaled by 1/sum-exp.
+// Pass 1: per (frame, 1/64 of the pixels) online max / sum-exp per part, lanes <-> parts (128 B coalesced rows).
+// Pass 2: per (frame, 1/32 of the pixels): GEMM [32 parts x K pixels] x [K x C] on v_mfma_f32_32x32x2_f32,
+//         A = exp(logit - max) computed on the fly, B = feature rows straight from HBM (read exactly once); each of
+//         the four waves takes a quarter of the workgroup's pixels, the four accumulator sets are added through LDS
+//         in a fixed order and one partial tile per workgroup goes to HBM.
+// Pass 3: deterministic reduction of the 32 partial tiles, scaled by 1/sum-exp.
+// The split is the same for every batch size, so a frame's result does not depend on the batch it is in (bit for
+// bit); it is fine enough for a single frame (32 + 64 workgroups; the loops are latency bound there - round 1's
+// 8 x 4 waves of 256 dependent trips took 0.365 ms per call at batch 1) and loads of four trips are requested before
+// the first is used.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_SCHUNKS = 16;
+constexpr int ATT_SCHUNKS = 64;
+constexpr int ATT_KSPLIT = 32;
 
 __global__ __launch_bounds__(256) void att_stats_kernel(const float* __restrict__ segm, int segm_cs, int H, int W,
                                                         float* __restrict__ ws) {
@@ -24,12 +31,19 @@ __global__ __launch_bounds__(256) void att_stats_kernel(const float* __restrict_
   const int npix = H * W, per = npix / ATT_SCHUNKS;
   const float* base = segm + (size_t)b * (2 * H) * (2 * W) * segm_cs + 1 + part;
   float m = -INFINITY, s = 0.f;
-  for (int q = chunk * per + grp; q < (chunk + 1) * per; q += 8) {
-    const int y = q / W, x = q % W;
-    const float v = base[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs];
-    const float nm = fmaxf(m, v);
-    s = s * expf(m - nm) + expf(v - nm);
-    m = nm;
+  for (int q = chunk * per + grp; q < (chunk + 1) * per; q += 32) {   // per % 32 == 0
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int qq = q + 8 * u, y = qq / W, x = qq % W;
+      v[u] = base[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float nm = fmaxf(m, v[u]);
+      s = s * expf(m - nm) + expf(v[u] - nm);
+      m = nm;
+    }
   }
   __shared__ float sm[8][32], ss[8][32];
   sm[grp][part] = m;
@@ -53,9 +67,13 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const float* __restrict__
   const int b = blockIdx.x, ks = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  // global max of my part over the 16 stat chunks
+  // global max of my part over the stat chunks
   float M = -INFINITY;
-  for (int c = 0; c < ATT_SCHUNKS; ++c) M = fmaxf(M, stats[(((size_t)b * ATT_SCHUNKS + c) * 32 + li) * 2]);
+  {
+    const float* st = stats + ((size_t)b * ATT_SCHUNKS * 32 + li) * 2;
+#pragma unroll 8
+    for (int c = 0; c < ATT_SCHUNKS; ++c) M = fmaxf(M, st[(size_t)c * 64]);
+  }
   const int npix = H * W;
   const int per_wave = npix / (ATT_KSPLIT * 4);
   const int q0 = (ks * 4 + wave) * per_wave;
@@ -66,28 +84,49 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const float* __restrict__
   for (int n = 0; n < NTILES; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-#pragma unroll 2
-  for (int q = q0 + lh; q < q0 + per_wave; q += 2) {
-    const int y = q / W, x = q % W;
-    const float a = expf(sbase[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs] - M);
-    const float* f = fbase + (size_t)q * feat_cs;
-    float bv[NTILES];
+  constexpr int U = NTILES > 8 ? 2 : 4;   // trips in flight (registers: U * NTILES feature values)
+  for (int q = q0 + lh; q < q0 + per_wave; q += 2 * U) {   // per_wave % 8 == 0
+    float lv[U], bv[U][NTILES];
 #pragma unroll
-    for (int n = 0; n < NTILES; ++n) bv[n] = f[n * 32];
+    for (int u = 0; u < U; ++u) {
+      const int qq = q + 2 * u, y = qq / W, x = qq % W;
+      lv[u] = sbase[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs];
+      const float* f = fbase + (size_t)qq * feat_cs;
 #pragma unroll
-    for (int n = 0; n < NTILES; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[n], acc[n], 0, 0, 0);
-  }
-  // D layout: col = lane&31 (channel within tile), row = (r&3)+8*(r>>2)+4*(lane>>5) (part)
-  float* o = part_ws + ((size_t)(b * ATT_KSPLIT + ks) * 4 + wave) * 32 * (NTILES * 32);
-#pragma unroll
-  for (int n = 0; n < NTILES; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      o[(size_t)p * (NTILES * 32) + n * 32 + li] = acc[n][r];
+      for (int n = 0; n < NTILES; ++n) bv[u][n] = f[n * 32];
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float a = expf(lv[u] - M);
+#pragma unroll
+      for (int n = 0; n < NTILES; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[u][n], acc[n], 0, 0, 0);
+    }
+  }
+  // the four waves' accumulator sets -> one partial tile, ((w0 + w1) + w2) + w3 per element, NH n-tiles per pass
+  // D layout: col = lane&31 (channel within tile), row = (r&3)+8*(r>>2)+4*(lane>>5) (part)
+  constexpr int NH = NTILES < 4 ? NTILES : 4;
+  __shared__ float red[4][NH * 1024];
+  float* o = part_ws + (size_t)(b * ATT_KSPLIT + ks) * 32 * (NTILES * 32);
+  for (int n0 = 0; n0 < NTILES; n0 += NH) {
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+      if (n >= n0 && n < n0 + NH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][(n - n0) * 1024 + r * 64 + lane] = acc[n][r];
+      }
+    __syncthreads();
+    const int cnt = (NTILES - n0 < NH ? NTILES - n0 : NH) * 1024;
+    for (int idx = threadIdx.x; idx < cnt; idx += 256) {
+      const float sum = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+      const int n = n0 + (idx >> 10), r = (idx >> 6) & 15, l = idx & 63;
+      const int p = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      o[(size_t)p * (NTILES * 32) + n * 32 + (l & 31)] = sum;
+    }
+    __syncthreads();
+  }
 }
 
+// grid (B, 32 * C / 256): one pooled value per thread, partial tiles summed in a fixed order
 __global__ __launch_bounds__(256) void att_reduce_kernel(const float* __restrict__ part_ws,
                                                          const float* __restrict__ stats, int C,
                                                          float* __restrict__ pooled) {
@@ -106,20 +145,29 @@ __global__ __launch_bounds__(256) void att_reduce_kernel(const float* __restrict
   }
   __syncthreads();
   const int n = 32 * C;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    float s = 0.f;
-    for (int k = 0; k < ATT_KSPLIT * 4; ++k) s += part_ws[((size_t)b * ATT_KSPLIT * 4 + k) * n + i];
-    pooled[(size_t)b * n + i] = s * inv[i / C];
+  const int i = blockIdx.y * 256 + threadIdx.x;
+  const float* src = part_ws + (size_t)b * ATT_KSPLIT * n + i;
+  float s = 0.f;
+  for (int k = 0; k < ATT_KSPLIT; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(k + u) * n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
   }
+  pooled[(size_t)b * n + i] = s * inv[i / C];
 }
 
 size_t attpool_ws_floats(int B, int C) {
-  return (size_t)B * ATT_SCHUNKS * 32 * 2 + (size_t)B * ATT_KSPLIT * 4 * 32 * C;
+  return (size_t)B * ATT_SCHUNKS * 32 * 2 + (size_t)B * ATT_KSPLIT * 32 * C;
 }
 
 hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, int H, int W,
-                          float* stats_ws, float* part_ws, float* pooled, hipStream_t s) {
-  if ((H * W) % (ATT_KSPLIT * 4 * 2) != 0 || (H * W) % ATT_SCHUNKS != 0) return hipErrorInvalidValue;
+                          float* ws, float* pooled, hipStream_t s) {
+  const int npix = H * W;
+  if (npix % (ATT_KSPLIT * 4 * 8) != 0 || npix % (ATT_SCHUNKS * 32) != 0 || (32 * C) % 256 != 0) return hipErrorInvalidValue;
+  float* stats_ws = ws;
+  float* part_ws = ws + (size_t)B * ATT_SCHUNKS * 32 * 2;
   hipLaunchKernelGGL(att_stats_kernel, dim3(B, ATT_SCHUNKS), dim3(256), 0, s, segm, segm_cs, H, W, stats_ws);
   if (C == 320)
     hipLaunchKernelGGL(att_pool_kernel<10>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
@@ -135,7 +183,7 @@ hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int
                        stats_ws, part_ws);
   else
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(att_reduce_kernel, dim3(B), dim3(256), 0, s, part_ws, stats_ws, C, pooled);
+  hipLaunchKernelGGL(att_reduce_kernel, dim3(B, 32 * C / 256), dim3(256), 0, s, part_ws, stats_ws, C, pooled);
   return hipGetLastError();
 }
 

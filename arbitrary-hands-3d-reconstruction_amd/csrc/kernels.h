@@ -57,9 +57,8 @@ hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, h
 
 // attention pooling: segm [B,2H,2W,segm_cs] logits (channels 1..32 at even pixels), feat [B,H,W,feat_cs] (C ch)
 // stats_ws: [B,32,2] (max, 1/sumexp); pooled [B,32,C]
-constexpr int ATT_KSPLIT = 8;
 hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, int H, int W,
-                          float* stats_ws, float* part_ws, float* pooled, hipStream_t s);
+                          float* ws, float* pooled, hipStream_t s);
 size_t attpool_ws_floats(int B, int C);
 
 // pare bias: pooled [B,32,320] -> per-frame bias row [B, biasP] for the 109->109 mix conv

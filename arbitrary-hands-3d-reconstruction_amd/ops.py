@@ -138,7 +138,7 @@ def attpool(segm, feat, channels):
     """segm NHWC [B,256,256,cs] logits, feat NHWC [B,128,128,cs]; -> pooled [B,32,channels]."""
     _need_cuda(segm, feat)
     B = segm.shape[0]
-    ws = torch.empty(B * 16 * 32 * 2 + B * 32 * 32 * channels, dtype=torch.float32, device=segm.device)
+    ws = torch.empty(int(_lib.lib().acrmi_attpool_ws_floats(B, channels)), dtype=torch.float32, device=segm.device)
     pooled = torch.empty(B, 32, channels, dtype=torch.float32, device=segm.device)
     _lib.check(_lib.lib().acrmi_attpool(_p(segm), segm.shape[-1], _p(feat), feat.shape[-1], channels, B, _p(ws),
                                         _p(pooled), _s(segm)))

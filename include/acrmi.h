@@ -195,7 +195,11 @@ int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
 int acrmi_bilinear2x(const float* in, int B, int H, int W, int in_cs, int C, float* out, int out_cs, void* stream);
 int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, const int* term_shift, int B, int H,
                    int W, int C, float* out, int out_cs, int relu, void* stream);
-int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* stats_ws,
+/* acr/model.py:103-113,126-136: pooled[b][part][c] = sum over the 128x128 pixels of softmax_pix(segm logit of the
+ * part at the even pixels of the 256x256 map) * feat[b][pix][c].  ws: device workspace of at least
+ * acrmi_attpool_ws_floats(B, C) floats. */
+size_t acrmi_attpool_ws_floats(int B, int C);
+int acrmi_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, float* ws,
                   float* pooled, void* stream);
 /* acr/model.py:141-164 per frame and hand: LocallyConnected2d (:559-569) on the 16 pooled part features of this side
  * (parts part0..part0+15 of pooled [B,32,C]; C = 320: 256 contact + 64 shape channels as the reference pools them),
