@@ -750,6 +750,10 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     }
     a.zeros = zeros[dev];
   }
+  {
+    hipError_t de = ensure_device_info();   // the CU count steers the item shape at small batches
+    if (de != hipSuccess) return de;
+  }
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.algo == 3) return launch_wino3(a, s);   // F(2x2,3x3), Cin <= 32, Cout = 32: weights packed for LDS residency
@@ -762,8 +766,6 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     // small batches: when two-n-tile items would not even fill the CUs once, one n-tile per item gives twice as many
     // items of half the length (256->256 at 16x16, one frame: 8 items of 85k cycles -> 16 of 45k; conv_bench --cfg 806
     // keeps two)
-    hipError_t de = ensure_device_info();
-    if (de != hipSuccess) return de;
     const long items2 = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16) * a.B * ((a.n_tiles + 1) / 2) * a.groups;
     const bool few = items2 < g_num_cus_dev[current_device()] && g_force_cfg != 806;
     const bool nt1 = n32 || a.cin8 * 8 <= 32 || odd33 || few;
@@ -784,13 +786,23 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     if (n32) return small ? launch_ws2<3, 1, 8, 16, 4, 1, 1, 1, 32, 2>(a, s) : launch_ws2<3, 1, 16, 16, 4, 2, 1, 1, 32, 2>(a, s);
     return small ? launch_ws2<3, 1, 8, 16, 2, 2, 2, 1, 32, 2>(a, s) : launch_ws2<3, 1, 16, 16, 4, 2, 1, 2, 32, 2>(a, s);
   }
+  // small batches (conv_bench --cfg 806 = the large-batch choice): the coarsest item shape that still gives every CU
+  // an item, else the finest - a 256->64 stride-2 layer on one frame is 32 items of 147k cycles with 64-cout items
+  const long cus = g_num_cus_dev[current_device()];
+  const long tiles8 = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16) * a.B * a.groups;
+  const long tiles16 = (long)((a.Ho + 15) / 16) * ((a.Wo + 15) / 16) * a.B * a.groups;
+  const int nb2 = (a.n_tiles + 1) / 2;
+  const bool fine = g_force_cfg != 806;
   if (a.ks == 3 && a.stride == 2) {
-    if (n32) return launch_ws2<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
+    if (n32 || (fine && tiles8 * nb2 < cus)) return launch_ws2<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
     return launch_ws2<3, 2, 8, 16, 2, 2, 2, 1, 16, 2>(a, s);
   }
   if (a.ks == 1 && a.stride == 1) {
-    if (n32) return small ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s) : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
-    return small ? launch_ws2<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s) : launch_ws2<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
+    if (n32) return (small || (fine && tiles16 < cus)) ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s)
+                                                        : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
+    if (fine && tiles8 * nb2 < cus) return launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s);
+    return (small || (fine && tiles16 * nb2 < cus)) ? launch_ws2<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s)
+                                                    : launch_ws2<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
   }
   return hipErrorInvalidValue;
 }
