@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ACRMI_LIB') or os.path.join(HERE, 'libacrmi.so')   # ACRMI_LIB: kernel experiments
 
-OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS = range(1, 10)
+OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
 OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF = 1, 2, 3, 4, 5, 6
 VERSION = 200
@@ -40,7 +40,7 @@ class HeadLayout(C.Structure):
 EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy', 'acrmi_load_weights',
            'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
-           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_attpool_ws_floats', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
+           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_attpool_ws_floats', 'acrmi_stem_conv', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias']
 
@@ -86,6 +86,7 @@ def lib():
                                  i32, vp]
     L.acrmi_attpool.argtypes = [f32p, i32, f32p, i32, i32, i32, f32p, f32p, vp]
     L.acrmi_attpool_ws_floats.argtypes = [i32, i32]
+    L.acrmi_stem_conv.argtypes = [vp, i32, i32, i32, f32p, f32p, f32p, i32, i32, i32, vp]
     L.acrmi_attpool_ws_floats.restype = C.c_size_t
     L.acrmi_profile_ops.argtypes = [vp, u8p, i32, vp, i32, vp]
     L.acrmi_tune.argtypes = [i32, i32]

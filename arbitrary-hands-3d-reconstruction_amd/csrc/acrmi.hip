@@ -184,6 +184,12 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       HIPCHK(c, launch_u8norm(img, (long)B * d.h * d.w, ptr(op.out_buf), s));
       return ACRMI_OK;
     }
+    case ACRMI_OP_STEM: {
+      const auto& d = desc(op.out_buf);
+      HIPCHK(c, launch_stem(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf), d.cs,
+                            op.out_coff, op.relu, s));
+      return ACRMI_OK;
+    }
     case ACRMI_OP_CONV: {
       const auto& di = desc(op.in_buf);
       const auto& dout = desc(op.out_buf);
@@ -288,7 +294,7 @@ static void op_rw(const acrmi_ctx* c, const acrmi_op& op, std::vector<int>& R, s
   auto r = [&](int id) { if (id >= 0) R.push_back(id); };
   auto w = [&](int id) { if (id >= 0) W.push_back(id); };
   switch (op.kind) {
-    case ACRMI_OP_U8NORM: w(op.out_buf); break;
+    case ACRMI_OP_U8NORM: case ACRMI_OP_STEM: w(op.out_buf); break;
     case ACRMI_OP_CONV: r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf); w(op.out_buf); break;
     case ACRMI_OP_FUSESUM: for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]); w(op.out_buf); break;
     case ACRMI_OP_BILINEAR2X: r(op.in_buf); w(op.out_buf); break;
@@ -397,7 +403,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
     if (op.mode < ACRMI_MODE_BOTH || op.mode > ACRMI_MODE_POINT) return fail(c, ACRMI_EINVAL, "op %d: bad mode", i);
     bool need_in = false, need_out = true;
     switch (op.kind) {
-      case ACRMI_OP_U8NORM: case ACRMI_OP_POW11: case ACRMI_OP_COORDFILL: break;
+      case ACRMI_OP_U8NORM: case ACRMI_OP_POW11: case ACRMI_OP_COORDFILL: case ACRMI_OP_STEM: break;
       case ACRMI_OP_CONV: case ACRMI_OP_BILINEAR2X: case ACRMI_OP_ATTPOOL: case ACRMI_OP_PAREBIAS: case ACRMI_OP_POINTHEADS:
         need_in = true;
         break;
@@ -435,6 +441,11 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       } else if (!w_ok(op.b_off, (long long)op.groups * n_tiles * 32)) {
         return fail(c, ACRMI_EINVAL, "op %d: bias outside the blob", i);
       }
+    }
+    if (op.kind == ACRMI_OP_STEM) {
+      if (op.cout != 64 || !stem_shape_ok(2 * bufs[op.out_buf].h, 2 * bufs[op.out_buf].w, bufs[op.out_buf].cs, op.out_coff))
+        return fail(c, ACRMI_EINVAL, "op %d: the stem kernel needs 64 output channels and a map of 8x64-pixel strips", i);
+      if (!w_ok(op.w_off, 14 * 2 * 64) || !w_ok(op.b_off, 64)) return fail(c, ACRMI_EINVAL, "op %d: stem weights outside the blob", i);
     }
     if (op.kind == ACRMI_OP_FUSESUM) {
       if (op.nterms < 1 || op.nterms > 4 || op.cout <= 0 || op.cout % 4 || op.out_coff + op.cout > bufs[op.out_buf].cs)
@@ -894,6 +905,14 @@ int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, co
   for (int t = 0; t < nterms; ++t) { f.term[t] = terms[t]; f.cs[t] = term_cs[t]; f.shift[t] = term_shift[t]; }
   hipError_t e = launch_fuse_sum(f, (hipStream_t)stream);
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "fuse_sum: %s", hipGetErrorString(e));
+}
+
+int acrmi_stem_conv(const uint8_t* img, int B, int H, int W, const float* w_packed, const float* bias, float* out,
+                    int out_cs, int out_coff, int relu, void* stream) {
+  if (!img || !w_packed || !bias || !out || B <= 0 || !stem_shape_ok(H, W, out_cs, out_coff))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_stem_conv: bad arguments (H %% 16, W %% 128, 64 channels inside out_cs)");
+  hipError_t e = launch_stem(img, B, H, W, w_packed, bias, out, out_cs, out_coff, relu, (hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "stem: %s", hipGetErrorString(e));
 }
 
 size_t acrmi_attpool_ws_floats(int B, int C) { return B > 0 && C > 0 ? attpool_ws_floats(B, C) : 0; }

@@ -41,6 +41,10 @@ void conv_set_phase_delay(int cycles);
 void conv_set_xcd_swizzle(int on);
 
 hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStream_t s);
+// stem.hip: uint8 RGB [B,H,W,3] -> relu(conv3x3 s2 (x/255*2-1) + b) [B,H/2,W/2,64 of out_cs]; wpk = packer.pack_stem
+bool stem_shape_ok(int H, int W, int out_cs, int out_coff);
+hipError_t launch_stem(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, float* out,
+                       int out_cs, int out_coff, int relu, hipStream_t s);
 hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,
                              int out_cs, int out_coff, hipStream_t s);
 struct FuseArgs {

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .packer import pack_conv, pack_wino3, n_tiles_for, winograd_weights, winograd2d_weights
+from .packer import pack_conv, pack_stem, pack_wino3, n_tiles_for, winograd_weights, winograd2d_weights
 
 
 def _p(t):
@@ -110,6 +110,19 @@ def u8norm(img):
     out = torch.empty(B, H, W, 4, dtype=torch.float32, device=img.device)
     src = img.contiguous()                 # bound to a local until the call has been queued
     _lib.check(_lib.lib().acrmi_u8norm(_p(src), B * H * W, _p(out), _s(src)))
+    return out
+
+
+def stem_conv(img, w, b, relu=True):
+    """uint8 RGB [B,H,W,3] on the device + conv1 filters [64,3,3,3] / bias [64] (host arrays, BN folded) ->
+    relu(conv3x3 stride 2 pad 1 of (img/255*2-1)) NHWC [B,H/2,W/2,64] (acr/model.py:832,589-603) in one kernel."""
+    _need_cuda(img)
+    B, H, W, _ = img.shape
+    wp, bp = pack_stem(np.asarray(w, np.float64), np.asarray(b, np.float64))
+    wd, bd = torch.from_numpy(wp).to(img.device), torch.from_numpy(bp).to(img.device)
+    out = torch.empty(B, H // 2, W // 2, 64, dtype=torch.float32, device=img.device)
+    src = img.contiguous()
+    _lib.check(_lib.lib().acrmi_stem_conv(_p(src), B, H, W, _p(wd), _p(bd), _p(out), 64, 0, int(relu), _s(src)))
     return out
 
 

@@ -89,6 +89,20 @@ def pack_wino3(w, b):
     return np.ascontiguousarray(u, np.float32).reshape(-1), bp
 
 
+def pack_stem(w, b):
+    """conv1 filters [64, 3, 3, 3] (BN folded) -> the register-resident A fragments of stem_kernel (csrc/stem.hip):
+    [step s 14][n-tile 2][lane 64] with cout = 32*n + (lane & 31), k = 2*s + (lane >> 5), k = (ky*3 + kx)*3 + c
+    (k = 27 is the zero pad of the 28-wide reduction); bias [64]."""
+    assert w.shape == (64, 3, 3, 3)
+    wk = np.zeros((64, 28))
+    wk[:, :27] = np.asarray(w, np.float64).transpose(0, 2, 3, 1).reshape(64, 27)       # [cout][ky][kx][c]
+    frag = wk.reshape(2, 32, 14, 2).transpose(2, 0, 3, 1)                               # [s][n][lh][li]
+    return np.ascontiguousarray(frag, np.float32).reshape(-1), np.asarray(b, np.float32).copy()
+
+
+# the stem (u8norm + conv1) as one kernel reading the uint8 image; False = the two generic ops of round 1
+STEM_FUSED = True
+
 WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
 
 
@@ -369,12 +383,19 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
     P = Program(sd)
     b = 'backbone.'
     # ---- stem -----------------------------------------------------------------------------------
-    x0 = P.buf(512, 512, 4)
-    P._op('u8norm', 0.0, kind=_lib.OP_U8NORM, out_buf=x0)
     w, bb = P.folded(b + 'conv1', b + 'bn1')
-    x = P.conv(b + 'conv1', x0, [(w, bb)], 3, 2, True, cin=3)
-    P.op_info[-1]['flops'] = 2.0 * 256 * 256 * 64 * 3 * 9
-    P.release(x0)
+    if STEM_FUSED:
+        x = P.buf(256, 256, 64)
+        wp, bp = pack_stem(w, bb)
+        P._op(b + 'conv1', 2.0 * 256 * 256 * 64 * 3 * 9, kind=_lib.OP_STEM, out_buf=x, cin=3, cout=64, ksize=3, stride=2,
+              relu=1, groups=1, w_off=P.blob.add(wp), b_off=P.blob.add(bp))
+        P.op_info[-1]['algo'] = 'stem_u8'
+    else:
+        x0 = P.buf(512, 512, 4)
+        P._op('u8norm', 0.0, kind=_lib.OP_U8NORM, out_buf=x0)
+        x = P.conv(b + 'conv1', x0, [(w, bb)], 3, 2, True, cin=3)
+        P.op_info[-1]['flops'] = 2.0 * 256 * 256 * 64 * 3 * 9
+        P.release(x0)
     x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True)
     P.release(x)
     x = x1

@@ -54,11 +54,14 @@ enum {
   ACRMI_OP_ATTPOOL = 6,  /* softmax-over-pixels weighted feature pooling (acr/model.py:103-113) */
   ACRMI_OP_PAREBIAS = 7, /* LocallyConnected2d + Linear + mix-conv pare bias (acr/model.py:145-164) */
   ACRMI_OP_COORDFILL = 8, /* init-time: write coord maps into 2 channels (acr/model.py:340-369) */
-  ACRMI_OP_POINTHEADS = 9 /* params/cam/prior head towers + 109x109 mix at the decoded centers only (one op per
+  ACRMI_OP_POINTHEADS = 9, /* params/cam/prior head towers + 109x109 mix at the decoded centers only (one op per
                              side = flags; in = backbone+coord buffer, res = pre-mix 109-ch map, out = params
                              map, aux = per-frame bias; w_off = 3 packed towers, w_off2 = mix weights);
                              acr/model.py:71-99,160-164 restricted to the pixels acr/result_parser.py:49-57,
                              141-145 samples */
+  ACRMI_OP_STEM = 10      /* uint8 image -> relu(conv3x3 stride 2 (x/255*2-1) + b), 3 -> 64 channels: U8NORM + the
+                             first CONV in one kernel (acr/model.py:832,589-603; in = the image, out = [B,H/2,W/2,>=64]);
+                             w_off = packer.pack_stem fragments [14][2][64], b_off = 64 biases */
 };
 
 /* acrmi_op.mode: which variant of the head program an op belongs to. */
@@ -192,6 +195,11 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
 int acrmi_preprocess(const uint8_t* bgr_dev, int n, int H, int W, uint8_t* out_rgb_dev, float* offsets_host,
                      void* stream);
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
+/* ACRMI_OP_STEM stand-alone: img uint8 RGB [B,H,W,3] (H % 16 == 0, W % 128 == 0) -> [relu](conv3x3 stride 2 pad 1 of
+ * (x/255*2-1) + bias) into channels out_coff..out_coff+63 of out [B,H/2,W/2,out_cs]; w_packed = packer.pack_stem(w
+ * [64,3,3,3]) (acr/model.py:832,589-603). */
+int acrmi_stem_conv(const uint8_t* img, int B, int H, int W, const float* w_packed, const float* bias, float* out,
+                    int out_cs, int out_coff, int relu, void* stream);
 int acrmi_bilinear2x(const float* in, int B, int H, int W, int in_cs, int C, float* out, int out_cs, void* stream);
 int acrmi_fuse_sum(int nterms, const float* const* terms, const int* term_cs, const int* term_shift, int B, int H,
                    int W, int C, float* out, int out_cs, int relu, void* stream);

@@ -314,6 +314,34 @@ def test_u8norm_bit_exact(ops):
     assert torch.equal(out[..., :3], ref) and (out[..., 3] == 0).all()
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 32, 128), (1, 16, 256), (3, 48, 128)])
+def test_stem_conv_reads_uint8_and_matches_fp64_conv(ops, B, H, W):
+    """csrc/stem.hip: relu(conv1(x/255*2-1)) straight from the uint8 frame (acr/model.py:832,589-603) against an fp64
+    convolution of u8norm's fp32 values - every border row/column included (the conv pads the NORMALISED map), extreme
+    pixel values at the corners."""
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g)
+    img[:, 0, 0] = 255
+    img[:, -1, -1] = 0
+    w = torch.randn(64, 3, 3, 3, generator=g, dtype=torch.float64) * 0.3
+    b = torch.randn(64, generator=g, dtype=torch.float64)
+    xn = ((img.float() / 255.) * 2.0 - 1.0).double().permute(0, 3, 1, 2)
+    for relu in (True, False):
+        ref = F.conv2d(xn, w, b, stride=2, padding=1)
+        ref = F.relu(ref) if relu else ref
+        out = ops.stem_conv(img.cuda(), w.numpy(), b.numpy(), relu=relu)
+        assert out.shape == (B, H // 2, W // 2, 64)
+        assert (_nchw(out, 64).double() - ref).abs().max().item() < 2e-5
+
+
+def test_stem_conv_rejects_shapes_outside_its_tiling(ops):
+    w, b = np.zeros((64, 3, 3, 3)), np.zeros(64)
+    with pytest.raises(ValueError):
+        ops.stem_conv(torch.zeros(1, 24, 128, 3, dtype=torch.uint8, device='cuda'), w, b)     # H % 16
+    with pytest.raises(ValueError):
+        ops.stem_conv(torch.zeros(1, 32, 64, 3, dtype=torch.uint8, device='cuda'), w, b)      # W % 128
+
+
 def test_bilinear2x_matches_torch(ops):
     x = torch.randn(2, 32, 24, 40)
     ref = F.interpolate(x, scale_factor=(2, 2), mode='bilinear', align_corners=True)
