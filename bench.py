@@ -235,7 +235,7 @@ def main():
         dom = [p for p in prof if p['kind'] == L.OP_CONV and p['ksize'] == 3 and p['stride'] == 1]
         dom_ms = sum(p['ms'] for p in dom)
         dom_flops = sum(p['flops'] for p in dom) * B
-        conv_ms = sum(p['ms'] for p in prof if p['kind'] == L.OP_CONV)
+        conv_ms = sum(p['ms'] for p in prof if p['kind'] in (L.OP_CONV, L.OP_STEM))
         total_ms = sum(p['ms'] for p in prof)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         # `achieved` here counts ALGORITHMIC (direct-convolution) FLOPs; Winograd executes 2.25x (1.5x) fewer of them
