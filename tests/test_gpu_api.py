@@ -361,8 +361,10 @@ def test_malformed_programs_are_rejected(synth_sd):
 
     def term(ops, heads):
         ops[fuse].term_buf[1] = len(prog['bufs']) + 3
+    stem = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_STEM)
     cases_ = [term, set_(conv, 'w_off', blob.size - 8), set_(conv, 'in_buf', -1), set_(conv, 'out_coff', 4096),
               set_(conv, 'cin', 4096), set_(conv, 'b_off', -5), set_(conv, 'mode', 7), set_(conv, 'ksize', 5),
+              set_(stem, 'cout', 32), set_(stem, 'w_off', blob.size - 100), set_(stem, 'out_coff', 2),
               lambda ops, heads: heads.center_buf.__setitem__(0, 999),
               lambda ops, heads: heads.params_buf.__setitem__(1, heads.center_buf[0])]
     for m in cases_:

@@ -280,6 +280,30 @@ def test_intermediate_backbone_taps_match_reference_golden(synth_sd, frames2):
     plain.close()
 
 
+def test_stem_kernel_lowering_matches_the_two_op_lowering(synth_sd, mano_tables, frames2):
+    """packer.STEM_FUSED: conv1 inside stem_kernel (reads the uint8 frame) vs round 1's u8norm + generic conv - the same
+    fp32 products in another summation order: the stem tap agrees to round-off, the results to well inside the budget."""
+    packer = pkg('packer')
+    x = torch.from_numpy(frames2).cuda()
+    res, taps = [], []
+    try:
+        for fused in (True, False):
+            packer.STEM_FUSED = fused
+            eng = pkg('engine').Engine(0)
+            eng.load_state_dict(synth_sd, max_batch=2, keep_taps=True)
+            assert any(o.kind == pkg('_lib').OP_STEM for o in eng.program['ops']) == fused
+            eng.load_mano(_flip_left(mano_tables))
+            res.append({k: v.clone() for k, v in eng.forward(x).items()})
+            taps.append(eng.buffer(eng.program['taps']['stem'], 2, 64).clone())
+            eng.close()
+    finally:
+        packer.STEM_FUSED = True
+    scale = float(taps[1].abs().max())
+    assert float((taps[0] - taps[1]).abs().max()) < 2e-5 * max(1.0, scale)
+    assert torch.equal(res[0]['slots'][..., :2], res[1]['slots'][..., :2])          # flags, centers
+    assert float((res[0]['verts'] - res[1]['verts']).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize('name', list(cases.STATE_CHECKPOINTS))
 def test_detection_states_through_the_network(name, mano_tables):
     """left-only / right-only / none / both-with-prior (centres <= 32 px apart) through the WHOLE
