@@ -22,7 +22,8 @@ struct ConvArgs {
   int algo;             // 0 direct; 1 Winograd F(2,3) along x (3x3 stride 1, weights packed with 3x4 taps);
                         // 2 Winograd F(2x2,3x3) (3x3 stride 1, weights packed with 4x4 taps)
   long long* dbg;       // optional device buffer for cycle stamps (tuning only)
-  int phase_delay;      // tuning: cycles the second half of the grid sleeps before starting (0 = off)
+  int phase_delay;      // tuning switches of the loader waves (acrmi_tune key 3): 8 = idle loader (timing ablation, wrong
+                        // results), 9 = loader at priority 0; 0 = off
   int xcd_swizzle;      // 1: work items are dealt to the XCDs in contiguous bands (see virtual_block, conv_mfma.hip)
   const float* zeros;   // >= 16 bytes of device zeros (source of halo / pad-channel lanes of conv_wino3's LDS-DMA loader)
 };

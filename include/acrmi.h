@@ -271,8 +271,12 @@ int acrmi_point_heads(acrmi_ctx* ctx, int B, void* stream);
  * (one untimed warm-up pass first; ops outside the active head mode report 0).  ms_out[n_ops]; returns n_ops or <0. */
 int acrmi_profile_ops(acrmi_ctx* ctx, const uint8_t* img_dev, int B, float* ms_out, int n_ms, void* stream);
 
-/* Tuning hook for kernel experiments (tools/conv_bench.py): key 0 = force a conv tile config id
- * (-1 = automatic selection).  Not part of the reference-facing surface. */
+/* Tuning hook for kernel experiments (tools/conv_bench.py, tools/ab_cfg.py); process-wide, not part of the
+ * reference-facing surface.  key 0: force a conv kernel variant (-1 = automatic selection; 8xx ids are listed next to
+ * the launchers in csrc/conv_mfma.hip, conv_wino2.inc, conv_wino3.inc - e.g. 805 second half on the compute waves,
+ * 806 large-batch item shapes at any batch, 838 no 16x32 wave tile, 839 no store waves); key 1: cycle stamps of
+ * workgroup 0 on/off; key 2: print them; key 3: loader-wave switches (8 idle loader - wrong results, 9 priority 0);
+ * key 4: XCD-banded item order on/off. */
 int acrmi_tune(int key, int value);
 
 #ifdef __cplusplus

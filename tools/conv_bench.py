@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--wino', action='store_true', help='3x3 stride-1 shapes through the Winograd F(2,3) kernel')
     ap.add_argument('--wino2', action='store_true', help='... through the 2-D Winograd F(2x2,3x3) kernel')
     ap.add_argument('--wino3', action='store_true', help='... Cin<=32/Cout=32 shapes through the LDS-resident F(2x2,3x3) kernel')
-    ap.add_argument('--phase', type=int, default=0, help='cycles the second half of the grid sleeps first')
+    ap.add_argument('--phase', type=int, default=0, help='loader-wave tuning switch: 8 = idle loader (timing ablation, wrong results), 9 = loader at priority 0')
     ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
     args = ap.parse_args()
     L = importlib.import_module(PKG + '._lib')
