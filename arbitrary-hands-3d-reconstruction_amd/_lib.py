@@ -40,7 +40,7 @@ class HeadLayout(C.Structure):
 EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy', 'acrmi_load_weights',
            'acrmi_set_program', 'acrmi_load_mano', 'acrmi_backbone_heads', 'acrmi_buffer_ptr', 'acrmi_decode',
            'acrmi_decode_maps', 'acrmi_mano', 'acrmi_forward', 'acrmi_conv2d', 'acrmi_u8norm', 'acrmi_bilinear2x',
-           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_attpool_ws_floats', 'acrmi_stem_conv', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
+           'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_attpool_ws_floats', 'acrmi_stem_conv', 'acrmi_stream_create', 'acrmi_stream_destroy', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias']
 
@@ -86,6 +86,8 @@ def lib():
                                  i32, vp]
     L.acrmi_attpool.argtypes = [f32p, i32, f32p, i32, i32, i32, f32p, f32p, vp]
     L.acrmi_attpool_ws_floats.argtypes = [i32, i32]
+    L.acrmi_stream_create.argtypes = [i32, C.POINTER(C.c_void_p)]
+    L.acrmi_stream_destroy.argtypes = [vp]
     L.acrmi_stem_conv.argtypes = [vp, i32, i32, i32, f32p, f32p, f32p, i32, i32, i32, vp]
     L.acrmi_attpool_ws_floats.restype = C.c_size_t
     L.acrmi_profile_ops.argtypes = [vp, u8p, i32, vp, i32, vp]

@@ -1037,6 +1037,28 @@ int acrmi_allgather(acrmi_ctx* c, void* nccl_comm, const float* send_dev, float*
   return ACRMI_OK;
 }
 
+// Plain HIP streams for hosts that have no stream API of their own at hand (Python: torch.cuda.Stream() instantiates
+// torch's whole pool of 32 streams per priority, and with that many streams alive the few in use share hardware
+// queues); engine.EnginePool runs its contexts on these.
+int acrmi_stream_create(int device, void** stream) {
+  if (!stream) return fail(nullptr, ACRMI_EINVAL, "acrmi_stream_create: null argument");
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess)
+    return fail(nullptr, ACRMI_EHIP, "acrmi_stream_create: cannot select device %d", device);
+  hipStream_t st = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  *stream = st;
+  return ACRMI_OK;
+}
+
+int acrmi_stream_destroy(void* stream) {
+  if (!stream) return ACRMI_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+}
+
 int acrmi_tune(int key, int value) {
   if (key == 0) { conv_force_cfg(value); return ACRMI_OK; }
   if (key == 3) { conv_set_phase_delay(value); return ACRMI_OK; }

@@ -36,9 +36,11 @@ class Engine(object):
         self._mano_tables = {}
 
     def close(self):
-        if self.ctx:
-            self.L.acrmi_destroy(self.ctx)
-            self.ctx = C.c_void_p()
+        # (the handle is dropped first and without touching module globals: during interpreter shutdown `C` may already
+        # be None, and an exception between the destroy and the reset would let a second __del__ destroy it again)
+        ctx, self.ctx = self.ctx, None
+        if ctx:
+            self.L.acrmi_destroy(ctx)
 
     def __del__(self):
         try:
@@ -50,7 +52,11 @@ class Engine(object):
     def load_state_dict(self, sd, max_batch=1, keep_taps=False):
         """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
         keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`)."""
-        prog = packer.lower(sd, keep_taps=keep_taps)
+        self.load_program(packer.lower(sd, keep_taps=keep_taps), max_batch)
+
+    def load_program(self, prog, max_batch=1):
+        """A program lowered elsewhere (packer.lower, or another Engine's `program`): the same packed weights and op
+        list in this context - an EnginePool lowers the checkpoint once."""
         blob = prog['blob']
         _lib.check(self.L.acrmi_load_weights(self.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), self.ctx)
         self.program = prog
@@ -238,8 +244,10 @@ class Engine(object):
                                      _stream(dev)), self.ctx)
         return verts, joints, center, extra
 
-    def forward(self, img, offsets=None, project=False, out=None):
-        """frames -> (slots [B,2,176], verts [B,2,778,3], joints [B,2,21,3][, verts_camed, pj2d, pj2d_org])."""
+    def forward(self, img, offsets=None, project=False, out=None, stream=None):
+        """frames -> (slots [B,2,176], verts [B,2,778,3], joints [B,2,21,3][, verts_camed, pj2d, pj2d_org]).
+        stream: raw hipStream_t (int) to queue the call on instead of torch's current stream; tensors this call
+        allocates still come from the current stream's pool."""
         img = self._check_img(img)
         B = img.shape[0]
         self.ensure_batch(B)
@@ -257,7 +265,8 @@ class Engine(object):
             offsets = offsets.to(dev, torch.float32).contiguous()
         _lib.check(self.L.acrmi_forward(self.ctx, _ptr(img), B, _ptr(offsets), _ptr(out['slots']), _ptr(out['verts']),
                                         _ptr(out['joints']), _ptr(out.get('verts_camed')), _ptr(out.get('pj2d')),
-                                        _ptr(out.get('pj2d_org')), _stream(dev)), self.ctx)
+                                        _ptr(out.get('pj2d_org')),
+                                        _stream(dev) if stream is None else C.c_void_p(stream)), self.ctx)
         return out
 
     def profile_ops(self, img):
@@ -270,6 +279,122 @@ class Engine(object):
         ops = self.program['ops']
         return [dict(info, ms=float(ms[i]), idx=i, ksize=int(ops[i].ksize), stride=int(ops[i].stride))
                 for i, info in enumerate(self.program['op_info'])]
+
+
+class EnginePool(object):
+    """n contexts on ONE GPU that take batches in turn, each on its own HIP stream (serving throughput).
+
+    A batch ends in a tail of kernels with few work items (attention pooling, the per-frame pare bias, decode, MANO: ~1
+    ms at batch 64) and the next one starts with pipeline fill; on one stream the 256 CUs idle through both.  With two
+    independent program instances in flight the hardware scheduler fills those gaps with the other batch's kernels:
+    39.8 -> 39.0 ms per batch of 64 (1607 -> 1642 frames/s), and the parallel lanes inside a context are no longer
+    needed (1 lane per context measured best).  Every batch is computed by one context exactly as Engine.forward does
+    (bit-identical results, tests/test_gpu_api.py); the price is a second set of activations (11 GB at batch 64 of the
+    288 GB) and one more batch of latency.  The reference has no counterpart (one nn.Module call per image,
+    acr/main.py:92-96).  A non-Python host does the same with two acrmi_ctx and two streams.
+
+        pool = EnginePool(0, n=2); pool.load_state_dict(sd, max_batch=64); pool.load_mano(tables)
+        t = pool.submit(frames)          # queued on the context's stream, behind the caller's current stream
+        out = pool.collect(t)            # the caller's current stream waits for that batch; dict of device tensors
+    At most n tickets may be outstanding.
+    The contexts run on plain HIP streams of the library (acrmi_stream_create): torch.cuda.Stream() would instantiate
+    torch's whole stream pool, and with that many streams alive the few in use share hardware queues."""
+
+    def __init__(self, device=0, n=2, first=None):
+        """first: an existing Engine to use as context 0 (its program, if loaded, is shared with the others)."""
+        if n < 1:
+            raise ValueError('n must be >= 1')
+        self.engines = ([first] if first is not None else []) + [Engine(device) for _ in range(n - (first is not None))]
+        self.device = self.engines[0].device
+        # plain HIP streams from the library (acrmi_stream_create), seen by torch as external streams
+        self._raw = []
+        for _ in range(n):
+            st = C.c_void_p()
+            _lib.check(self.engines[0].L.acrmi_stream_create(self.device.index, C.byref(st)))
+            self._raw.append(st)
+        self.streams = [torch.cuda.ExternalStream(st.value, device=self.device) for st in self._raw]
+        self._turn = 0
+        self._busy = [None] * n
+
+    def __len__(self):
+        return len(self.engines)
+
+    def close(self, keep_first=False):
+        """Releases the streams and the contexts (keep_first: all but context 0, e.g. an Engine passed as `first`)."""
+        if self._raw:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize()
+            self.streams = []
+            L = _lib.lib()
+            for st in self._raw:
+                L.acrmi_stream_destroy(st)
+            self._raw = []
+        for e in self.engines[1 if keep_first else 0:]:
+            e.close()
+        self.engines = []      # (keep_first: context 0 stays open and belongs to whoever passed it in)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd, max_batch=1, lanes=1):
+        """sd = None: share the program context 0 already holds."""
+        prog = self.engines[0].program if sd is None else packer.lower(sd)
+        if prog is None:
+            raise _lib.AcrmiError('no checkpoint loaded')
+        for e in self.engines:
+            if e.program is not prog:
+                e.load_program(prog, max_batch)
+            else:
+                e.ensure_batch(max_batch)
+            e.set_lanes(lanes)
+
+    def load_mano(self, tables=None):
+        """tables = None: context 0's tables."""
+        for e in self.engines:
+            if tables is not None:
+                e.load_mano(tables)
+            elif e is not self.engines[0]:
+                for name, t in self.engines[0]._mano_tables.items():
+                    e.load_mano_side(name, t)
+
+    def configure(self, fn):
+        """fn(engine) on every context (options: set_conf_thresh, set_center_idx, set_point_heads, ...)."""
+        for e in self.engines:
+            fn(e)
+
+    def submit(self, img, offsets=None, project=False, out=None):
+        i = self._turn
+        if self._busy[i] is not None:
+            raise RuntimeError('collect() the ticket submitted %d calls ago first' % len(self.engines))
+        self._turn = (i + 1) % len(self.engines)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))   # the frames (and the out tensors) as the caller left them
+        st = self.streams[i]
+        st.wait_event(ready)
+        # (no `with torch.cuda.stream(st)`: tensors must not come from the caching allocator's pool of a stream that
+        # close() destroys; everything this call allocates belongs to the caller's stream, which collect() orders behind
+        # the batch)
+        res = self.engines[i].forward(img, offsets=offsets, project=project, out=out, stream=self._raw[i].value)
+        done = torch.cuda.Event()
+        done.record(st)
+        ticket = {'slot': i, 'event': done, 'out': res, 'img': img}    # (img: kept alive until the batch has run)
+        self._busy[i] = ticket
+        return ticket
+
+    def release(self, ticket):
+        """Frees the ticket's context for the next submit without making any stream wait: for callers that order
+        their consumers on ticket['event'] themselves (parallel.ShardedRunner queues the all-gather behind it)."""
+        if self._busy[ticket['slot']] is ticket:
+            self._busy[ticket['slot']] = None
+        return ticket['event']
+
+    def collect(self, ticket):
+        self.release(ticket)
+        torch.cuda.current_stream(self.device).wait_event(ticket['event'])
+        return ticket['out']
 
 
 class _DevArray(object):

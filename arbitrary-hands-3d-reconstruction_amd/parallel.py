@@ -122,13 +122,16 @@ class ShardedRunner(object):
             raise RuntimeError('collect() the ticket submitted two calls ago first (results are double-buffered)')
         self._turn ^= 1
         flat, views, gathered = self._set(n_local, turn)
-        self.local_forward(frames_local, views)
+        ret = self.local_forward(frames_local, views)
         ticket = {'turn': turn, 'n_local': n_local, 'event': None, 'work': None}
         if self.device.type == 'cuda':
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(self.device)
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(self.device))
+            # local_forward ran on the current stream - or, when it returns an event (engine.EnginePool: the batch runs
+            # on one of the pool's own streams), that event marks its end
+            done = ret if isinstance(ret, torch.cuda.Event) else torch.cuda.Event()
+            if done is not ret:
+                done.record(torch.cuda.current_stream(self.device))
             self._comm_stream.wait_event(done)             # the gather starts when this batch's MANO has finished
             with torch.cuda.stream(self._comm_stream):
                 if self.transport == 'c':

@@ -118,23 +118,20 @@ def latency(eng, frames, views_for, batches=(1, 8), iters=20):
     return out
 
 
-def point_heads_rate(eng, frames, views, steps, warmup):
+def point_heads_rate(set_point_heads, run_steps, B, steps, warmup):
     """Reported NEXT TO the headline, never as it: the same frames -> slots/verts/joints with the
     params/cam/prior head towers evaluated only at the pixels the decode samples (ACRMI_OPT_POINT_HEADS).  The dense
     head maps are not produced in this mode, so `value` above stays the full path."""
-    B = frames.shape[0]
-    eng.set_point_heads(True)
+    set_point_heads(True)
     try:
-        for _ in range(max(1, warmup)):
-            eng.forward(frames, out=views)
+        run_steps(max(1, warmup))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.forward(frames, out=views)
+        run_steps(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     finally:
-        eng.set_point_heads(False)
+        set_point_heads(False)
     return {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
             'note': 'head towers at decoded centers only; same slots/verts/joints within fp32 round-off; '
                     'dense params/prior maps not produced'}
@@ -149,7 +146,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 / batch-8 latency measurement (profiling runs)')
     ap.add_argument('--no-point-heads', action='store_true', help='skip the separately reported point-heads variant')
-    ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default)')
+    ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default, 1 per context with --pipeline >= 2)')
+    ap.add_argument('--pipeline', type=int, default=2, help='contexts taking batches in turn on their own streams (engine.EnginePool): the tail of one batch overlaps the head of the next; 1 = one context')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
     args = ap.parse_args()
 
@@ -178,33 +176,52 @@ def main():
     tables = synth.make_mano_tables(seed=1)
     tables['left']['shapedirs'] = tables['left']['shapedirs'].copy()
     tables['left']['shapedirs'][:, 0, :] *= -1          # acr/mano_wrapper.py:35
+    npipe = max(1, args.pipeline)
+    if use_dist:
+        npipe = min(npipe, 2)                   # ShardedRunner double-buffers its result sets
     eng = pkg('engine').Engine(local_rank)
     eng.load_state_dict(sd, max_batch=B)
     eng.load_mano(tables)
-    frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False)).cuda()   # resident in HBM
     eng.set_lanes(args.lanes)
+    frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False)).cuda()   # resident in HBM
+    pool = None
+    if npipe > 1:
+        # two contexts take the batches in turn, each on its own stream (engine.EnginePool): every batch is one context's
+        # Engine.forward, the low-occupancy tail of batch k overlaps the head of batch k+1
+        pool = pkg('engine').EnginePool(local_rank, n=npipe, first=eng)
+        pool.load_state_dict(None, max_batch=B, lanes=args.lanes or 1)
+        pool.load_mano(None)
 
-    flat, views = parallel.alloc_result(B, eng.device)
+    vsets = [parallel.alloc_result(B, eng.device)[1] for _ in range(npipe)]
+    views = vsets[0]
     runner = None
     if use_dist:
         # one all-gather per batch, queued on a side stream into the second of two result buffers: batch k's gather
         # overlaps batch k+1's backbone (parallel.ShardedRunner.submit / collect); every gather of the K timed
         # steps has completed when the closing synchronize returns
-        runner = parallel.ShardedRunner(lambda f, v: eng.forward(f, out=v), eng.device, engine=eng)
+        if pool is not None:
+            local = lambda f, v: pool.release(pool.submit(f, out=v))      # -> the event the gather waits for
+        else:
+            local = lambda f, v: eng.forward(f, out=v)
+        runner = parallel.ShardedRunner(local, eng.device, engine=eng)
 
     def run_steps(n):
-        if runner is None:
+        if runner is None and pool is None:
             for _ in range(n):
                 eng.forward(frames, out=views)
             return
-        pending = None
-        for _ in range(n):
-            ticket = runner.submit(frames)
-            if pending is not None:
-                runner.collect(pending)
-            pending = ticket
-        if pending is not None:
-            runner.collect(pending)
+        pending = []
+        depth = 1 if runner is not None else len(pool) - 1     # tickets left outstanding behind a submit
+        for i in range(n):
+            if runner is not None:
+                pending.append((runner, runner.submit(frames)))
+            else:
+                pending.append((pool, pool.submit(frames, out=vsets[i % npipe])))
+            while len(pending) > depth:
+                who, t = pending.pop(0)
+                who.collect(t)
+        for who, t in pending:
+            who.collect(t)
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
@@ -276,11 +293,22 @@ def main():
                'dtype': 'f32', 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
                'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, fp32',
                           'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
+                          'contexts_in_turn': npipe,
                           'gflop_per_frame': GFLOP_PER_FRAME},
                'roofline': roofline}
         if world == 1 and not args.no_point_heads:
-            out['point_heads'] = point_heads_rate(eng, frames, views, args.steps, args.warmup)
-        if world == 1 and not args.no_latency:
+            setter = (lambda on: pool.configure(lambda e: e.set_point_heads(on))) if pool is not None else eng.set_point_heads
+            out['point_heads'] = point_heads_rate(setter, run_steps, B, args.steps, args.warmup)
+        if world == 1 and not use_dist and not args.no_latency:
+            # single calls (the way the reference is driven): one context with the library's lanes.  Measured AFTER the
+            # pool is gone, and the pool is created BEFORE any lane stream exists: streams created behind three or more
+            # others run their kernels measurably less concurrently (tools/pipeline_probe.py: 1620 -> 1585 frames/s
+            # for the pool when a 4-lane call came first; 8 ms instead of 3.4 per batch-1 call with torch's stream pool
+            # alive)
+            if pool is not None:
+                pool.close(keep_first=True)
+                pool = None
+            eng.set_lanes(0)
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, tables)

@@ -271,6 +271,11 @@ int acrmi_point_heads(acrmi_ctx* ctx, int B, void* stream);
  * (one untimed warm-up pass first; ops outside the active head mode report 0).  ms_out[n_ops]; returns n_ops or <0. */
 int acrmi_profile_ops(acrmi_ctx* ctx, const uint8_t* img_dev, int B, float* ms_out, int n_ms, void* stream);
 
+/* A non-blocking HIP stream on `device` / its release - for hosts without a stream API of their own (the Python
+ * package runs the contexts of an EnginePool on these instead of torch's pooled streams). */
+int acrmi_stream_create(int device, void** stream);
+int acrmi_stream_destroy(void* stream);
+
 /* Tuning hook for kernel experiments (tools/conv_bench.py, tools/ab_cfg.py); process-wide, not part of the
  * reference-facing surface.  key 0: force a conv kernel variant (-1 = automatic selection; 8xx ids are listed next to
  * the launchers in csrc/conv_mfma.hip, conv_wino2.inc, conv_wino3.inc, conv_ws2.inc - e.g. 806 large-batch item shapes

@@ -332,9 +332,58 @@ def test_sharded_runner_over_rccl_world_size_1(synth_sd, mano_tables, frames2):
             for k in ('slots', 'verts', 'joints'):
                 assert torch.equal(r0[k], want[k]), (transport, k)
                 assert torch.equal(r1[k], want[k].flip(0)), (transport, k)
+        # the batches computed by an EnginePool (two contexts in turn on their own streams): the gather waits for the
+        # event the pool returns
+        pool = pkg('engine').EnginePool(0, n=2)
+        pool.load_state_dict(synth_sd, max_batch=2)
+        pool.load_mano(t)
+        runner = parallel.ShardedRunner(lambda f, views: pool.release(pool.submit(f, out=views)), pool.device, engine=eng)
+        tickets = [runner.submit(x)]
+        got = []
+        for i in range(1, 5):
+            tickets.append(runner.submit(x.flip(0).contiguous() if i & 1 else x))
+            got.append(runner.collect(tickets[i - 1]))
+        got.append(runner.collect(tickets[-1]))
+        torch.cuda.synchronize()
+        for i, r in enumerate(got):
+            for k in ('slots', 'verts', 'joints'):
+                assert torch.equal(r[k], want[k].flip(0) if i & 1 else want[k]), (i, k)
+        pool.close()
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_engine_pool_batches_equal_single_context(synth_sd, mano_tables):
+    """engine.EnginePool: contexts taking batches in turn on their own streams return, batch for batch, exactly what one
+    Engine.forward call returns - three contexts, seven different batches, at most three tickets outstanding; a fourth
+    submit without a collect is refused."""
+    t = {k: dict(v) for k, v in mano_tables.items()}
+    t['left']['shapedirs'] = t['left']['shapedirs'].copy()
+    t['left']['shapedirs'][:, 0, :] *= -1
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=3)
+    eng.load_mano(t)
+    pool = pkg('engine').EnginePool(0, n=3)
+    pool.load_state_dict(synth_sd, max_batch=3)
+    pool.load_mano(t)
+    batches = [torch.from_numpy(pkg('synth').make_frames(3, seed=40 + i, structured=True)).cuda() for i in range(7)]
+    want = [{k: v.clone() for k, v in eng.forward(b).items()} for b in batches]
+    pending, got = [], []
+    for b in batches:
+        pending.append(pool.submit(b))
+        if len(pending) == 3:
+            with pytest.raises(RuntimeError):
+                pool.submit(b)
+            got.append({k: v.clone() for k, v in pool.collect(pending.pop(0)).items()})
+    while pending:
+        got.append({k: v.clone() for k, v in pool.collect(pending.pop(0)).items()})
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for k in ('slots', 'verts', 'joints'):
+            assert torch.equal(w[k], g[k]), k
+    pool.close()
+    eng.close()
 
 
 def test_malformed_programs_are_rejected(synth_sd):
