@@ -9,10 +9,10 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# one stream (--lanes 1) and no point-heads pass: with the default parallel lanes two kernels share the GPU, a
+# one context on one stream (--pipeline 1 --lanes 1) and no point-heads pass: with the default parallel lanes two kernels share the GPU, a
 # kernel's duration in the trace (and its PMC counters) then include its neighbour - bench.py's own per-kernel
 # figures (roofline.*) come from a single-stream pass (acrmi_profile_ops) as well
-BENCH="python $R/bench.py --no-cpu-baseline --no-point-heads --no-latency --lanes 1"
+BENCH="python $R/bench.py --no-cpu-baseline --no-point-heads --no-latency --lanes 1 --pipeline 1"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/${TAG}_stats" -o bench -- $BENCH --steps 5 --warmup 2 > "$OUT/${TAG}_stats.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/${TAG}_pmc_fetch" -o p -- $BENCH --steps 1 --warmup 1 > "$OUT/${TAG}_pmc_fetch.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/${TAG}_pmc_write" -o p -- $BENCH --steps 1 --warmup 1 > "$OUT/${TAG}_pmc_write.log" 2>&1

@@ -3,7 +3,7 @@
 
     python tools/summarize_pmc.py <fetch_dir> <write_dir> <out.json>
 The two directories hold `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs (separate passes, no
-other trace domains) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-point-heads --no-latency --lanes 1`.  Counter unit: KiB.
+other trace domains) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-point-heads --no-latency --lanes 1 --pipeline 1`.  Counter unit: KiB.
 gfx950 correction (MI355X_MICROARCH.md, calibrated here on u8norm: 24589 KiB reported for 50.33 MB read):
 FETCH_SIZE under-reports wide coalesced reads by 2 -> doubled; WRITE_SIZE is exact.
 """
@@ -44,7 +44,7 @@ def main():
                       'hbm_bytes_per_launch': fb + wb}
     with open(out, 'w') as f:
         json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on '
-                   '`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-point-heads --no-latency --lanes 1`, B=64; FETCH_SIZE doubled per '
+                   '`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-point-heads --no-latency --lanes 1 --pipeline 1`, B=64; FETCH_SIZE doubled per '
                    'MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads), WRITE_SIZE exact',
                    'kernels': kernels}, f, indent=1)
     print(json.dumps(kernels, indent=1))
