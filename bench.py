@@ -299,6 +299,20 @@ def main():
         if world == 1 and not args.no_point_heads:
             setter = (lambda on: pool.configure(lambda e: e.set_point_heads(on))) if pool is not None else eng.set_point_heads
             out['point_heads'] = point_heads_rate(setter, run_steps, B, args.steps, args.warmup)
+        if world == 1 and not use_dist and pool is not None and not args.no_latency:
+            # the same K batches on ONE context with the library's lanes (what `value` was before round 2's EnginePool)
+            eng.set_lanes(args.lanes)
+            for _ in range(args.warmup):
+                eng.forward(frames, out=views)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.forward(frames, out=views)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            out['single_context'] = {'value': round(B * args.steps / dt1, 2), 'unit': 'frames/s',
+                                     'ms_per_step': round(dt1 / args.steps * 1e3, 3),
+                                     'note': 'one context, batches back to back on one stream (+ its parallel lanes)'}
         if world == 1 and not use_dist and not args.no_latency:
             # single calls (the way the reference is driven): one context with the library's lanes.  Measured AFTER the
             # pool is gone, and the pool is created BEFORE any lane stream exists: streams created behind three or more
