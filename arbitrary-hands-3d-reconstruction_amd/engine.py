@@ -289,7 +289,7 @@ class EnginePool(object):
     independent program instances in flight the hardware scheduler fills those gaps with the other batch's kernels:
     39.8 -> 39.0 ms per batch of 64 (1607 -> 1642 frames/s), and the parallel lanes inside a context are no longer
     needed (1 lane per context measured best).  Every batch is computed by one context exactly as Engine.forward does
-    (bit-identical results, tests/test_gpu_api.py); the price is a second set of activations (11 GB at batch 64 of the
+    (bit-identical results, tests/test_gpu_api.py); the price is a second set of activations (9.9 GB at batch 64 of the
     288 GB) and one more batch of latency.  The reference has no counterpart (one nn.Module call per image,
     acr/main.py:92-96).  A non-Python host does the same with two acrmi_ctx and two streams.
 
