@@ -370,6 +370,10 @@ class EnginePool(object):
         if self._busy[i] is not None:
             raise RuntimeError('collect() the ticket submitted %d calls ago first' % len(self.engines))
         self._turn = (i + 1) % len(self.engines)
+        # host-side conversions run on the caller's stream: they must be queued before `ready` is recorded
+        img = self.engines[i]._check_img(img)
+        if offsets is not None:
+            offsets = offsets.to(self.device, torch.float32).contiguous()
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))   # the frames (and the out tensors) as the caller left them
         st = self.streams[i]

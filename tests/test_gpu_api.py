@@ -370,6 +370,12 @@ def test_engine_pool_batches_equal_single_context(synth_sd, mano_tables):
     batches = [torch.from_numpy(pkg('synth').make_frames(3, seed=40 + i, structured=True)).cuda() for i in range(7)]
     want = [{k: v.clone() for k, v in eng.forward(b).items()} for b in batches]
     pending, got = [], []
+    offs = torch.tensor([[512., 512., 0, 0, 0, 0, 0, 0, 0, 0]] * 3)          # a HOST tensor: converted before the hand-over
+    proj = pool.collect(pool.submit(batches[0], offsets=offs, project=True))
+    ref = eng.forward(batches[0], offsets=offs, project=True)
+    torch.cuda.synchronize()
+    for k in ('verts_camed', 'pj2d', 'pj2d_org'):
+        assert torch.equal(proj[k], ref[k]), k
     for b in batches:
         pending.append(pool.submit(b))
         if len(pending) == 3:
