@@ -279,7 +279,7 @@ int acrmi_stream_destroy(void* stream);
 /* Tuning hook for kernel experiments (tools/conv_bench.py, tools/ab_cfg.py); process-wide, not part of the
  * reference-facing surface.  key 0: force a conv kernel variant (-1 = automatic selection; 8xx ids are listed next to
  * the launchers in csrc/conv_mfma.hip, conv_wino2.inc, conv_wino3.inc, conv_ws2.inc - e.g. 806 large-batch item shapes
- * at any batch, 838 no 16x32 wave tile, 839 no store waves); key 1: cycle stamps of
+ * at any batch, 837 the 16x32 wave tile of conv_wino3b_kernel, 839 no store waves); key 1: cycle stamps of
  * workgroup 0 on/off; key 2: print them; key 3: loader-wave switches (8 idle loader - wrong results, 9 priority 0);
  * key 4: XCD-banded item order on/off. */
 int acrmi_tune(int key, int value);

@@ -149,7 +149,7 @@ WINO3_CASES = [
 
 
 @pytest.mark.parametrize('case', WINO3_CASES, ids=lambda c: 'wino3_B%d_%dto32_%dx%d' % c[:4])
-@pytest.mark.parametrize('cfg', [-1, 838, 833, 832, 836, 837], ids=['default', 'tile8x16_lds_dma_loader', 'register_loader', 'tile16x16_8waves', 'lds_dma_1wave', 'wave_tile_16x32'])
+@pytest.mark.parametrize('cfg', [-1, 839, 833, 832, 836, 837], ids=['default', 'no_store_waves', 'register_loader', 'tile16x16_8waves', 'lds_dma_1wave', 'wave_tile_16x32'])
 def test_conv2d_winograd_lds_matches_torch(ops, case, cfg):
     """conv_wino3_kernel (F(2x2,3x3), taps resident in LDS, 16 positions per wave on v_mfma_f32_16x16x4_f32) vs an
     fp64 direct convolution, in both workgroup shapes; input / residual / output in channel slices of wider buffers."""
