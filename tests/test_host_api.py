@@ -125,6 +125,19 @@ def test_pad_geometry_matches_imgaug_rule():
         u.img_preprocess(np.zeros((8, 8, 3), np.float32))
 
 
+def test_engine_and_pool_refuse_to_run_without_a_gpu():
+    """No CPU fallback: without a GPU the context objects raise (the product path never routes through oracle/)."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    engine = pkg('engine')
+    with pytest.raises(pkg('_lib').AcrmiError):
+        engine.Engine(0)
+    with pytest.raises(pkg('_lib').AcrmiError):
+        engine.EnginePool(0, n=2)
+    with pytest.raises(ValueError):
+        engine.EnginePool(0, n=0)
+
+
 def test_config_plumbed_and_rejected_options():
     """flags the kernels honour are accepted (centermap_conf_thresh, align_idx, mano_mesh_root_align,
     smooth_coeff); flags they cannot honour raise instead of being silently ignored."""
