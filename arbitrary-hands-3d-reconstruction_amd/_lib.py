@@ -62,6 +62,11 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, f32p, u8p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
     L.acrmi_version.restype = C.c_int
+    if L.acrmi_version() != VERSION:
+        # the argument lists below are those of VERSION: a stale build (or an ACRMI_LIB override from another round)
+        # would be called with shifted arguments
+        raise AcrmiError('%s is ABI version %d, this package binds version %d: rebuild it (`python __graft_entry__.py build`)'
+                         % (LIB_PATH, L.acrmi_version(), VERSION))
     L.acrmi_last_error.restype = C.c_char_p
     L.acrmi_last_error.argtypes = [vp]
     L.acrmi_create.argtypes = [C.POINTER(vp), i32]

@@ -33,7 +33,7 @@ class ACR(object):
         self._build_model_(state_dict, mano_tables, device, max_batch)
         if self.temporal_optimization:
             # acr/main.py:45-47: one filter set per hand type; the state lives in the engine's context
-            self.filter_dict = create_OneEuroFilter(a.smooth_coeff, engine=self.model.engine())
+            self.filter_dict = create_OneEuroFilter(a.smooth_coeff, engine=self.model.engine)
 
     def _build_model_(self, state_dict, mano_tables, device, max_batch):
         """acr/main.py:57-63"""
@@ -106,7 +106,9 @@ class ACR(object):
         if offsets is None:
             offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(B, 1)
         eng.set_point_heads(point_heads)
-        eng.set_temporal(bool(self.temporal_optimization))     # frames of the batch = one video stream, in order
+        # frames of the batch = one video stream, in order (smooth_coeff travels with the call: a reloaded checkpoint
+        # builds a new context)
+        eng.set_temporal(bool(self.temporal_optimization), smooth_coeff=self._args.smooth_coeff)
         try:
             out = eng.forward(rgb_u8_frames, offsets=offsets, project=True)
         finally:

@@ -155,12 +155,27 @@ class DeviceOneEuro(object):
     `acrmi_smooth` updates both hands' poses/betas in one launch between decode and MANO."""
 
     def __init__(self, engine, smooth_coeff):
-        self.engine, self.smooth_coeff = engine, float(smooth_coeff)
-        engine.set_temporal(False, smooth_coeff=smooth_coeff)
-        engine.smooth_reset()
+        # engine: an Engine, or a callable returning the CURRENT one (acr.model.ACR.engine: a checkpoint reload
+        # replaces the context, and the filter must follow it instead of calling into the closed one)
+        self._engine = engine if callable(engine) else (lambda: engine)
+        self.smooth_coeff = float(smooth_coeff)
+        self._bound = None
+        self._bind()
+
+    def _bind(self):
+        eng = self._engine()
+        if eng is not self._bound:        # first use, or the model rebuilt its engine: a fresh stream state there
+            eng.set_temporal(eng.temporal, smooth_coeff=self.smooth_coeff)
+            eng.smooth_reset()
+            self._bound = eng
+        return eng
+
+    @property
+    def engine(self):
+        return self._bind()
 
     def process_slots(self, slots):
-        return self.engine.smooth(slots)
+        return self._bind().smooth(slots)
 
 
 def create_OneEuroFilter(smooth_coeff, engine=None):

@@ -77,8 +77,8 @@ def validate(ns):
     if list(ns.kernel_sizes) != [5]:
         # CenterMap's NMS window (acr/result_parser.py:199,207-216): the decode kernel implements the 5x5 pool only
         raise ValueError('kernel_sizes=%r: only the 5x5 center NMS (kernel_sizes=[5]) is implemented' % (ns.kernel_sizes,))
-    if ns.max_hand != 2:
-        raise ValueError('max_hand=%r: one left and one right hand per frame (top-1 per center map) is implemented' % ns.max_hand)
+    # (max_hand is not validated: the reference reads it only under train_flag, acr/result_parser.py:221-224 -
+    # inference always takes the top-1 center per map, whatever the reference's default of 4 says)
     if not (isinstance(ns.align_idx, int) and 0 <= ns.align_idx <= 20):
         raise ValueError('align_idx must be a joint index 0..20')
     if ns.model_precision not in ('fp32',):

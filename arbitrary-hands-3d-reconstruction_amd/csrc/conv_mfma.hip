@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace acrmi {
@@ -666,8 +667,16 @@ static int current_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
   return dev;
 }
+// Lazily created per-device state (CU count, zero buffer, the per-kernel "dynamic LDS attribute set" flags) is guarded
+// by one recursive mutex held for the whole of launch_conv / launch_point_heads: several contexts / host threads of
+// one process may make their first launch at the same time (EnginePool, acr.main.ACR(device=...)), and a flag must not
+// be visible before the attribute it stands for is set.  Uncontended cost per launch: one lock/unlock pair (~20 ns)
+// next to a ~4 us launch.
+static std::recursive_mutex g_init_mutex;
+std::recursive_mutex& launch_mutex() { return g_init_mutex; }
 static hipError_t ensure_device_info() {
   const int dev = current_device();
+  std::lock_guard<std::recursive_mutex> lock(g_init_mutex);
   if (g_num_cus_dev[dev]) return hipSuccess;
   int n = 0;
   hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -678,6 +687,7 @@ static hipError_t ensure_device_info() {
 // true the first time `flags` (a per-kernel-instantiation array) is asked about the current device
 bool first_use_on_device(unsigned char* flags) {
   const int dev = current_device();
+  std::lock_guard<std::recursive_mutex> lock(g_init_mutex);
   if (flags[dev]) return false;
   flags[dev] = 1;
   return true;
@@ -736,6 +746,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 // Tile selection.  N32: one 32-cout tile per wave (Cout <= 32); N64: two.
 // Small frames (<=16x16 outputs) take the 8x16 pixel tile so a batch still fills 256 CUs.
 hipError_t launch_conv(ConvArgs a, hipStream_t s) {
+  std::lock_guard<std::recursive_mutex> launch_lock(g_init_mutex);
   a.dbg = g_dbg;
   a.phase_delay = g_phase_delay;
   static const char* swz_env = getenv("ACRMI_XCD_SWIZZLE");      // A/B runs: 0 = round-robin item order
@@ -743,10 +754,18 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   {   // halo / pad-channel lanes of the LDS-DMA loaders read zeros from here (one small allocation per device)
     static float* zeros[MAX_DEVICES] = {};
     const int dev = current_device();
+    std::lock_guard<std::recursive_mutex> lock(g_init_mutex);
     if (!zeros[dev]) {
-      hipError_t e = hipMalloc(&zeros[dev], 256);
+      float* z = nullptr;
+      hipError_t e = hipMalloc(&z, 256);
       if (e != hipSuccess) return e;
-      if ((e = hipMemset(zeros[dev], 0, 256)) != hipSuccess) return e;
+      // the memset runs on the null stream; the kernels that read the buffer run on non-blocking streams, which do
+      // not order themselves behind it: wait for it here, once per device
+      if ((e = hipMemset(z, 0, 256)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        (void)hipFree(z);
+        return e;
+      }
+      zeros[dev] = z;
     }
     a.zeros = zeros[dev];
   }

@@ -699,6 +699,7 @@ hipError_t launch_point_heads(const PointArgs& a, hipStream_t s) {
   static unsigned char attr_set[MAX_DEVICES] = {};
   constexpr int LDS_BYTES = TP_LDS_FLOATS * (int)sizeof(float);
   static_assert(TP_XIN >= (49 + 25 + 9 + 1 + TP_WAVES) * 64, "window buffers alias the dead x34 window");
+  std::lock_guard<std::recursive_mutex> lock(launch_mutex());
   if (first_use_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_point_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace acrmi {
 
@@ -32,6 +33,8 @@ struct ConvArgs {
 // instantiation) is asked about the current device
 constexpr int MAX_DEVICES = 64;
 bool first_use_on_device(unsigned char* flags);
+// held by a launcher from the first_use_on_device() test until the attribute is set (and by launch_conv throughout)
+std::recursive_mutex& launch_mutex();
 
 // returns hipSuccess or the launch error; cout tiles etc. derived inside
 hipError_t launch_conv(ConvArgs a, hipStream_t s);

@@ -32,6 +32,7 @@ class Engine(object):
         self.conf_thresh = 0.35
         self.center_idx = 9
         self.temporal = False
+        self.smooth_coeff = None          # None = the library default (4.0)
         self.comm_ranks = 0
         self._mano_tables = {}
 
@@ -101,6 +102,7 @@ class Engine(object):
         (acr/main.py:69-83); the frames of a call are then one video stream in order."""
         if smooth_coeff is not None:
             _lib.check(self.L.acrmi_set_option_f(self.ctx, _lib.OPT_SMOOTH_COEFF, float(smooth_coeff)), self.ctx)
+            self.smooth_coeff = float(smooth_coeff)
         _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_TEMPORAL, int(bool(on))), self.ctx)
         self.temporal = bool(on)
 
@@ -154,6 +156,7 @@ class Engine(object):
         self.set_center_idx(other.center_idx)
         if other.lanes:
             self.set_lanes(other.lanes)
+        self.set_temporal(other.temporal, smooth_coeff=other.smooth_coeff)
 
     def load_mano_side(self, name, t):
         """One side's tables (mano/manolayer.py:61-102 buffers) -> HBM, blend-shape tables transposed."""
@@ -315,6 +318,7 @@ class EnginePool(object):
         self.streams = [torch.cuda.ExternalStream(st.value, device=self.device) for st in self._raw]
         self._turn = 0
         self._busy = [None] * n
+        self._inflight = []      # released tickets whose batch may still be running: their tensors stay referenced
 
     def __len__(self):
         return len(self.engines)
@@ -384,15 +388,23 @@ class EnginePool(object):
         res = self.engines[i].forward(img, offsets=offsets, project=project, out=out, stream=self._raw[i].value)
         done = torch.cuda.Event()
         done.record(st)
-        ticket = {'slot': i, 'event': done, 'out': res, 'img': img}    # (img: kept alive until the batch has run)
+        # Everything the batch reads or writes stays referenced by the ticket until its event has completed: the call
+        # runs on the pool's stream, so torch's caching allocator (which only knows the caller's stream) would hand a
+        # dropped `img` / `offsets` block to the caller's next allocation while the kernels still read it.
+        ticket = {'slot': i, 'event': done, 'out': res, 'img': img, 'offsets': offsets}
         self._busy[i] = ticket
         return ticket
+
+    def _reap(self):
+        self._inflight = [t for t in self._inflight if not t['event'].query()]
 
     def release(self, ticket):
         """Frees the ticket's context for the next submit without making any stream wait: for callers that order
         their consumers on ticket['event'] themselves (parallel.ShardedRunner queues the all-gather behind it)."""
         if self._busy[ticket['slot']] is ticket:
             self._busy[ticket['slot']] = None
+            self._reap()
+            self._inflight.append(ticket)      # kept until its event has completed (see submit)
         return ticket['event']
 
     def collect(self, ticket):

@@ -146,9 +146,12 @@ def test_config_plumbed_and_rejected_options():
     ns = cfg.parse_args(base + ['--centermap_conf_thresh', '0.2', '--align_idx', '0', '--mano_mesh_root_align', 'false',
                                 '--smooth_coeff', '3.0'])
     assert ns.centermap_conf_thresh == 0.2 and ns.align_idx == 0 and ns.mano_mesh_root_align is False
-    for bad in (['--kernel_sizes', '3'], ['--kernel_sizes', '5', '7'], ['--max_hand', '4'], ['--align_idx', '21']):
+    for bad in (['--kernel_sizes', '3'], ['--kernel_sizes', '5', '7'], ['--align_idx', '21']):
         with pytest.raises(ValueError):
             cfg.parse_args(base + bad)
+    # the reference's own default max_hand=4 (acr/config.py:161) is only read under train_flag
+    # (acr/result_parser.py:221-224): carrying it over must not be an error
+    assert cfg.parse_args(base + ['--max_hand', '4']).max_hand == 4
 
 
 def test_state_dict_surface_without_gpu(synth_sd):
