@@ -9,7 +9,7 @@ import torch
 
 from ..config import args, validate
 from ..engine import Engine
-from ..schema import state_dict_schema
+from ..schema import state_dict_schema, width_of
 from .result_parser import ResultParser, rows_from_slots
 
 
@@ -19,17 +19,22 @@ class ACR(object):
         self._retired = None
         self._result_parser = ResultParser()
         self.params_num = self._result_parser.params_num
-        self._sd = OrderedDict()
-        for k, shp in state_dict_schema().items():       # zero-initialised until a checkpoint is loaded
-            self._sd[k] = torch.zeros(shp, dtype=torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
-        for k in self._sd:
-            if k.endswith('running_var') or (k.endswith('.weight') and (k[:-7] + '.running_var') in self._sd):
-                self._sd[k].fill_(1.0)
+        self._init_sd(int(kwargs.get('width', 32)))
         self._device = device
         self._max_batch = max_batch
         self._engine = None
         self._loaded = False
         self.training = False
+
+    def _init_sd(self, width):
+        """Zero-initialised tensors with the reference's key names (HRNet width 32; 48 = the BASELINE configs[4] variant)."""
+        self._width = width
+        self._sd = OrderedDict()
+        for k, shp in state_dict_schema(width).items():       # zero-initialised until a checkpoint is loaded
+            self._sd[k] = torch.zeros(shp, dtype=torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
+        for k in self._sd:
+            if k.endswith('running_var') or (k.endswith('.weight') and (k[:-7] + '.running_var') in self._sd):
+                self._sd[k].fill_(1.0)
 
     # ---- nn.Module-like surface ----------------------------------------------------------------
     def state_dict(self):
@@ -38,6 +43,8 @@ class ACR(object):
     def load_state_dict(self, sd, strict=True):
         from ..packer import strip_prefix, check_state_dict
         sd = strip_prefix(sd)
+        if width_of(sd) != self._width and width_of(sd) in (32, 48):
+            self._init_sd(width_of(sd))                  # an HRNet-W48 checkpoint re-shapes the module
         if strict:
             check_state_dict(sd)
         missing = [k for k in self._sd if k not in sd]
@@ -78,7 +85,7 @@ class ACR(object):
         options, so wrappers holding the model (MANOWrapper) keep working."""
         if self._engine is None:
             eng = Engine(self._device)
-            eng.load_state_dict(self._sd, max_batch=max(self._max_batch, min_batch))
+            eng.load_state_dict(self._sd, max_batch=max(self._max_batch, min_batch), precision=self._args.model_precision)
             a = self._args
             eng.set_conf_thresh(a.centermap_conf_thresh)          # CenterMap.conf_thresh (acr/result_parser.py:198-205)
             eng.set_center_idx(a.align_idx if a.mano_mesh_root_align else None)
@@ -97,7 +104,7 @@ class ACR(object):
         """acr/model.py:831-865: uint8 [B,512,512,3] -> [B,32,128,128] (NCHW copy of the resident buffer)."""
         eng = self.engine(image.shape[0])
         B = eng.backbone_heads(image)
-        return eng.buffer(eng.program['heads'].backbone_buf, B, 32).permute(0, 3, 1, 2).contiguous()
+        return eng.buffer(eng.program['heads'].backbone_buf, B, self._width).permute(0, 3, 1, 2).float().contiguous()
 
     @torch.no_grad()
     def head_forward(self, image):

@@ -81,8 +81,10 @@ def validate(ns):
     # inference always takes the top-1 center per map, whatever the reference's default of 4 says)
     if not (isinstance(ns.align_idx, int) and 0 <= ns.align_idx <= 20):
         raise ValueError('align_idx must be a joint index 0..20')
-    if ns.model_precision not in ('fp32',):
-        raise ValueError('model_precision %r: this build computes in fp32 only' % ns.model_precision)
+    if ns.model_precision not in ('fp32', 'fp16', 'bf16'):
+        # acr/config.py:96: fp32 (configs/demo.yml) | fp16 (the argparse default: autocast, acr/model.py:33-37);
+        # bf16 = the same 16-bit program on the other gfx950 MFMA type (packer.lower)
+        raise ValueError("model_precision %r: 'fp32', 'fp16' or 'bf16'" % ns.model_precision)
     return ns
 
 

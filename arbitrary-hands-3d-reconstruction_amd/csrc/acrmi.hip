@@ -178,6 +178,11 @@ int acrmi_load_weights(acrmi_ctx* c, const float* blob, size_t n) {
 static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s) {
   auto ptr = [&](int id) -> float* { return id >= 0 ? c->buf_ptr[id] : nullptr; };
   auto desc = [&](int id) -> const acrmi_buffer_desc& { return c->bufs[id]; };
+  // buffer `id` advanced by `coff` ELEMENTS of its storage type (the pointers stay typed float*: they are opaque here)
+  auto eptr = [&](int id, int coff) -> float* {
+    if (id < 0) return nullptr;
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(c->buf_ptr[id]) + (size_t)coff * (c->bufs[id].dtype ? 2 : 4));
+  };
   switch (op.kind) {
     case ACRMI_OP_U8NORM: {
       const auto& d = desc(op.out_buf);
@@ -186,8 +191,12 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
     }
     case ACRMI_OP_STEM: {
       const auto& d = desc(op.out_buf);
-      HIPCHK(c, launch_stem(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf), d.cs,
-                            op.out_coff, op.relu, s));
+      if (d.dtype)
+        HIPCHK(c, launch_stem_h16(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf),
+                                  d.cs, op.out_coff, op.relu, d.dtype, s));
+      else
+        HIPCHK(c, launch_stem(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf), d.cs,
+                              op.out_coff, op.relu, s));
       return ACRMI_OK;
     }
     case ACRMI_OP_CONV: {
@@ -208,6 +217,8 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
       a.algo = op.flags & 3;
+      a.dtype = di.dtype;                                    // 16-bit input: conv_h16.hip
+      a.out_f32 = di.dtype != ACRMI_DT_F32 && dout.dtype == ACRMI_DT_F32;
       HIPCHK(c, launch_conv(a, s));
       return ACRMI_OK;
     }
@@ -215,31 +226,37 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       const auto& dout = desc(op.out_buf);
       FuseArgs f{};
       f.nterms = op.nterms; f.B = B; f.H = dout.h; f.W = dout.w; f.C = op.cout; f.out_cs = dout.cs; f.relu = op.relu;
-      f.out = ptr(op.out_buf) + op.out_coff;
+      f.out = eptr(op.out_buf, op.out_coff);
       for (int t = 0; t < op.nterms; ++t) {
-        f.term[t] = ptr(op.term_buf[t]) + op.term_coff[t];
+        f.term[t] = eptr(op.term_buf[t], op.term_coff[t]);
         f.cs[t] = desc(op.term_buf[t]).cs;
         f.shift[t] = op.term_shift[t];
       }
-      HIPCHK(c, launch_fuse_sum(f, s));
+      if (dout.dtype) HIPCHK(c, launch_fuse_sum_h16(f, dout.dtype, s));
+      else HIPCHK(c, launch_fuse_sum(f, s));
       return ACRMI_OK;
     }
     case ACRMI_OP_BILINEAR2X: {
       const auto& di = desc(op.in_buf);
-      HIPCHK(c, launch_bilinear2x(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
-                                  desc(op.out_buf).cs, op.out_coff, s));
+      if (di.dtype)
+        HIPCHK(c, launch_bilinear2x_h16(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
+                                        desc(op.out_buf).cs, op.out_coff, di.dtype, s));
+      else
+        HIPCHK(c, launch_bilinear2x(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
+                                    desc(op.out_buf).cs, op.out_coff, s));
       return ACRMI_OK;
     }
     case ACRMI_OP_POW11: {
       const auto& d = desc(op.out_buf);
-      HIPCHK(c, launch_pow11(ptr(op.out_buf), (long)B * d.h * d.w, d.cs, op.out_coff, s));
+      if (d.dtype) HIPCHK(c, launch_pow11_h16(ptr(op.out_buf), (long)B * d.h * d.w, d.cs, op.out_coff, d.dtype, s));
+      else HIPCHK(c, launch_pow11(ptr(op.out_buf), (long)B * d.h * d.w, d.cs, op.out_coff, s));
       return ACRMI_OK;
     }
     case ACRMI_OP_ATTPOOL: {
       const auto& ds = desc(op.in_buf);     // segm logits
       const auto& df = desc(op.res_buf);    // features
-      HIPCHK(c, launch_attpool(ptr(op.in_buf), ds.cs, ptr(op.res_buf) + op.res_coff, df.cs, op.cin, B, df.h, df.w,
-                               c->att_ws, ptr(op.out_buf), s));
+      HIPCHK(c, launch_attpool(ptr(op.in_buf), ds.cs, eptr(op.res_buf, op.res_coff), df.cs, op.cin, B, df.h, df.w,
+                               c->att_ws, ptr(op.out_buf), s, df.dtype));
       return ACRMI_OK;
     }
     case ACRMI_OP_PAREBIAS: {
@@ -257,7 +274,8 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
     }
     case ACRMI_OP_COORDFILL: {
       const auto& d = desc(op.out_buf);
-      HIPCHK(c, launch_coordfill(ptr(op.out_buf), c->max_batch, d.h, d.w, d.cs, op.out_coff, s));
+      if (d.dtype) HIPCHK(c, launch_coordfill_h16(ptr(op.out_buf), c->max_batch, d.h, d.w, d.cs, op.out_coff, d.dtype, s));
+      else HIPCHK(c, launch_coordfill(ptr(op.out_buf), c->max_batch, d.h, d.w, d.cs, op.out_coff, s));
       return ACRMI_OK;
     }
     case ACRMI_OP_POINTHEADS: {
@@ -378,10 +396,17 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   if (!c->weights) return fail(c, ACRMI_ESTATE, "acrmi_set_program: load weights first");
   ON_DEVICE(c);
   // ---- validate before anything is allocated: a malformed program must fail here, not fault on the device
+  int prog_dt = ACRMI_DT_F32;      // the one 16-bit storage type of the program, if any
   for (int i = 0; i < n_bufs; ++i) {
     const auto& d = bufs[i];
-    if (d.h <= 0 || d.w <= 0 || d.cs <= 0 || d.cs % 4) return fail(c, ACRMI_EINVAL, "buffer %d: bad geometry", i);
+    if (d.dtype < ACRMI_DT_F32 || d.dtype > ACRMI_DT_BF16) return fail(c, ACRMI_EINVAL, "buffer %d: unknown dtype %d", i, d.dtype);
+    if (d.h <= 0 || d.w <= 0 || d.cs <= 0 || d.cs % (d.dtype ? 8 : 4)) return fail(c, ACRMI_EINVAL, "buffer %d: bad geometry", i);
+    if (d.dtype) {
+      if (prog_dt && prog_dt != d.dtype) return fail(c, ACRMI_EINVAL, "buffer %d: f16 and bf16 buffers in one program", i);
+      prog_dt = d.dtype;
+    }
   }
+  auto bdt = [&](int id) { return id >= 0 ? bufs[id].dtype : (int)ACRMI_DT_F32; };
   auto buf_ok = [&](int id) { return id >= 0 && id < n_bufs; };
   auto w_ok = [&](long long off, long long n) { return off >= 0 && n >= 0 && (unsigned long long)(off + n) <= c->n_weights; };
   {
@@ -389,6 +414,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
                        heads->prior_buf[0], heads->prior_buf[1], heads->segm_buf, heads->backbone_buf};
     for (int id : hb)
       if (!buf_ok(id)) return fail(c, ACRMI_EINVAL, "head layout references buffer %d of %d", id, n_bufs);
+    for (int k = 0; k < 7; ++k)      // decode / attention pooling / the host read these as fp32 (acr/model.py:56-62 .float())
+      if (bufs[hb[k]].dtype != ACRMI_DT_F32) return fail(c, ACRMI_EINVAL, "head layout: head maps must be fp32 buffers");
     if (bufs[heads->params_buf[0]].cs < 109 || bufs[heads->params_buf[1]].cs < 109 || bufs[heads->prior_buf[0]].cs < 106 ||
         bufs[heads->prior_buf[1]].cs < 106)
       return fail(c, ACRMI_EINVAL, "head layout: params/prior buffers are too narrow");
@@ -414,10 +441,21 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       return fail(c, ACRMI_EINVAL, "op %d (kind %d): missing input/output buffer", i, op.kind);
     if (op.in_coff < 0 || op.out_coff < 0 || op.res_coff < 0) return fail(c, ACRMI_EINVAL, "op %d: negative channel offset", i);
     if (op.kind == ACRMI_OP_CONV) {
-      if (op.in_coff % 4 || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2 || op.cin <= 0 || op.cout <= 0 ||
+      const int idt = bufs[op.in_buf].dtype, odt = bufs[op.out_buf].dtype;
+      if (op.in_coff % (idt ? 8 : 4) || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2 || op.cin <= 0 || op.cout <= 0 ||
           op.groups <= 0 || (op.ksize == 1 && op.stride != 1))
         return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
       const int algo = op.flags & 3;
+      // 16-bit input: direct kernel only; the output is 16-bit too or fp32 (a head exit; 1x1 and 3x3 stride 1), a residual
+      // has the type of the output.  fp32 input: everything fp32.
+      if (idt ? (algo != 0 || (odt != idt && odt != ACRMI_DT_F32) || (odt == ACRMI_DT_F32 && op.stride != 1) ||
+                 (op.groups > 1 && op.cin % 2))
+              : odt != ACRMI_DT_F32)
+        return fail(c, ACRMI_EINVAL, "op %d: conv buffer types do not fit (in %d, out %d, algo %d)", i, idt, odt, algo);
+      if (op.res_buf >= 0 && bufs[op.res_buf].dtype != odt)
+        return fail(c, ACRMI_EINVAL, "op %d: the residual must have the type of the output", i);
+      if (op.bias_per_frame && buf_ok(op.aux_buf) && bufs[op.aux_buf].dtype != ACRMI_DT_F32)
+        return fail(c, ACRMI_EINVAL, "op %d: the per-frame bias must be fp32", i);
       if (algo != 0 && !(op.ksize == 3 && op.stride == 1))
         return fail(c, ACRMI_EINVAL, "op %d: algo %d needs a 3x3 stride-1 convolution", i, algo);
       if (algo == 3 && (op.groups != 1 || op.cin > 32 || op.cout != 32 || op.bias_per_frame || bufs[op.out_buf].h % 8 ||
@@ -433,7 +471,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         return fail(c, ACRMI_EINVAL, "op %d: output/residual buffer geometry does not match the convolution", i);
       const long long n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       const long long taps = algo >= 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize);
-      const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ((op.cin + 7) / 8) * n_tiles * 256;
+      const long long ksteps = idt ? (op.cin + 15) / 16 : (op.cin + 7) / 8;      // 1 KiB weight fragments per tap and n-tile
+      const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ksteps * n_tiles * 256;
       if (!w_ok(op.w_off, wn)) return fail(c, ACRMI_EINVAL, "op %d: packed weights outside the blob", i);
       if (op.bias_per_frame) {
         if (!buf_ok(op.aux_buf) || bufs[op.aux_buf].cs < op.groups * op.cout)
@@ -443,15 +482,19 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       }
     }
     if (op.kind == ACRMI_OP_STEM) {
+      if (bufs[op.out_buf].dtype && (bufs[op.out_buf].cs % 8 || op.out_coff % 8))
+        return fail(c, ACRMI_EINVAL, "op %d: a 16-bit stem output needs channel stride / offset in multiples of 8", i);
       if (op.cout != 64 || !stem_shape_ok(2 * bufs[op.out_buf].h, 2 * bufs[op.out_buf].w, bufs[op.out_buf].cs, op.out_coff))
         return fail(c, ACRMI_EINVAL, "op %d: the stem kernel needs 64 output channels and a map of 8x64-pixel strips", i);
       if (!w_ok(op.w_off, 14 * 2 * 64) || !w_ok(op.b_off, 64)) return fail(c, ACRMI_EINVAL, "op %d: stem weights outside the blob", i);
     }
     if (op.kind == ACRMI_OP_FUSESUM) {
-      if (op.nterms < 1 || op.nterms > 4 || op.cout <= 0 || op.cout % 4 || op.out_coff + op.cout > bufs[op.out_buf].cs)
+      const int vq = bufs[op.out_buf].dtype ? 8 : 4;      // elements per 16-byte vector
+      if (op.nterms < 1 || op.nterms > 4 || op.cout <= 0 || op.cout % vq || op.out_coff % vq || op.out_coff + op.cout > bufs[op.out_buf].cs)
         return fail(c, ACRMI_EINVAL, "op %d: bad fuse-sum geometry", i);
       for (int t = 0; t < op.nterms; ++t) {
-        if (!buf_ok(op.term_buf[t]) || op.term_coff[t] < 0 || op.term_shift[t] < 0 || op.term_shift[t] > 3 ||
+        if (!buf_ok(op.term_buf[t]) || op.term_coff[t] < 0 || bufs[op.term_buf[t]].dtype != bufs[op.out_buf].dtype ||
+            op.term_coff[t] % vq || op.term_shift[t] < 0 || op.term_shift[t] > 3 ||
             op.term_coff[t] + op.cout > bufs[op.term_buf[t]].cs ||
             (bufs[op.term_buf[t]].h << op.term_shift[t]) != bufs[op.out_buf].h ||
             (bufs[op.term_buf[t]].w << op.term_shift[t]) != bufs[op.out_buf].w)
@@ -459,7 +502,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       }
     }
     if (op.kind == ACRMI_OP_BILINEAR2X &&
-        (op.cin <= 0 || op.cin % 4 || op.in_coff % 4 || op.out_coff % 4 || op.in_coff + op.cin > bufs[op.in_buf].cs ||
+        (op.cin <= 0 || bufs[op.in_buf].dtype != bufs[op.out_buf].dtype || op.cin % (bufs[op.in_buf].dtype ? 8 : 4) ||
+         op.in_coff % (bufs[op.in_buf].dtype ? 8 : 4) || op.out_coff % (bufs[op.in_buf].dtype ? 8 : 4) || op.in_coff + op.cin > bufs[op.in_buf].cs ||
          op.out_coff + op.cin > bufs[op.out_buf].cs || bufs[op.out_buf].h != 2 * bufs[op.in_buf].h ||
          bufs[op.out_buf].w != 2 * bufs[op.in_buf].w))
       return fail(c, ACRMI_EINVAL, "op %d: bad bilinear geometry", i);
@@ -467,11 +511,17 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         (op.kind == ACRMI_OP_COORDFILL && op.out_coff + 2 > bufs[op.out_buf].cs))
       return fail(c, ACRMI_EINVAL, "op %d: channel outside the buffer", i);
     if (op.kind == ACRMI_OP_ATTPOOL) {
+      if (buf_ok(op.res_buf) && (bufs[op.in_buf].dtype != ACRMI_DT_F32 || bufs[op.out_buf].dtype != ACRMI_DT_F32 ||
+                                 (bufs[op.res_buf].dtype != ACRMI_DT_F32 && op.cin != 256)))
+        return fail(c, ACRMI_EINVAL, "op %d: attention pooling reads fp32 logits, writes fp32, and pools 256 channels of a 16-bit map", i);
       if (!buf_ok(op.res_buf) || (op.cin != 32 && op.cin != 64 && op.cin != 256 && op.cin != 320) ||
           op.res_coff + op.cin > bufs[op.res_buf].cs || bufs[op.in_buf].cs < 33 || bufs[op.in_buf].h != 2 * bufs[op.res_buf].h ||
           bufs[op.in_buf].w != 2 * bufs[op.res_buf].w || (long long)bufs[op.out_buf].h * bufs[op.out_buf].w * bufs[op.out_buf].cs < 32LL * op.cin)
         return fail(c, ACRMI_EINVAL, "op %d: bad attention-pool geometry", i);
     }
+    if ((op.kind == ACRMI_OP_PAREBIAS || op.kind == ACRMI_OP_POINTHEADS || op.kind == ACRMI_OP_U8NORM) &&
+        (bdt(op.in_buf) || bdt(op.out_buf) || bdt(op.res_buf) || bdt(op.aux_buf)))
+      return fail(c, ACRMI_EINVAL, "op %d (kind %d): fp32 buffers only", i, op.kind);
     if (op.kind == ACRMI_OP_PAREBIAS) {
       const long long shape_n = (op.cin == 320 ? 64 : 256) * 16;
       if ((op.cin != 256 && op.cin != 320) || (op.flags != 0 && op.flags != 16) || bufs[op.out_buf].cs < 109 || bufs[op.out_buf].cs > 256 ||
@@ -496,7 +546,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   c->buf_ptr.assign(n_bufs, nullptr);
   for (int i = 0; i < n_bufs; ++i) {
     const auto& d = bufs[i];
-    const size_t bytes = (size_t)max_batch * d.h * d.w * d.cs * sizeof(float);
+    const size_t bytes = (size_t)max_batch * d.h * d.w * d.cs * (d.dtype ? 2 : sizeof(float));
     hipError_t e = hipMalloc(&c->buf_ptr[i], bytes);
     if (e != hipSuccess) return fail(c, ACRMI_ENOMEM, "hipMalloc(%zu) for buffer %d: %s", bytes, i, hipGetErrorString(e));
     HIPCHK(c, hipMemset(c->buf_ptr[i], 0, bytes));
@@ -742,6 +792,11 @@ void* acrmi_buffer_ptr(acrmi_ctx* c, int buf, int* h, int* w, int* cs) {
   return c->buf_ptr[buf];
 }
 
+int acrmi_buffer_dtype(acrmi_ctx* c, int buf) {
+  if (!c || !c->have_program || buf < 0 || buf >= (int)c->bufs.size()) return -1;
+  return c->bufs[buf].dtype;
+}
+
 int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs, const float* l_params,
                       const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
                       int B, float conf_thresh, float* slots, void* stream) {
@@ -858,6 +913,41 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   a.n_tiles = cout <= 32 ? 1 : ((cout + 63) / 64) * 2;
   a.bias_fstride = bias_frame_stride;
   a.algo = algo;
+  hipError_t e = launch_conv(a, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
+  return ACRMI_OK;
+}
+
+int acrmi_conv2d_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int cin, const void* w_packed,
+                     const float* bias, int bias_frame_stride, const void* res, int res_cs, int res_coff, void* out,
+                     int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups, int dtype,
+                     int out_f32, void* stream) {
+  if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0 ||
+      (dtype != ACRMI_DT_F16 && dtype != ACRMI_DT_BF16))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: bad arguments");
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1) || (out_f32 && stride != 1))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: 3x3 s1/s2 and 1x1 s1 (fp32 output: stride 1 only); got k%d s%d", ksize, stride);
+  const int oq = out_f32 ? 4 : 8;      // elements per 16-byte vector of the output / residual
+  if (in_cs % 8 || in_coff % 8 || (groups > 1 && cin % 2) || out_cs % oq || (res && res_cs % oq))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: channel strides must be multiples of 16 bytes");
+  if (in_coff < 0 || out_coff < 0 || res_coff < 0 || in_coff + groups * cin > in_cs || out_coff + groups * cout > out_cs ||
+      (res && res_coff + groups * cout > res_cs) || bias_frame_stride < 0 ||
+      (bias_frame_stride > 0 && bias_frame_stride < groups * cout))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: channel slice outside its tensor's channel stride");
+  ConvArgs a{};
+  a.in = reinterpret_cast<const float*>(in); a.w = reinterpret_cast<const float*>(w_packed); a.bias = bias;
+  a.res = reinterpret_cast<const float*>(res); a.out = reinterpret_cast<float*>(out);
+  a.B = B; a.H = H; a.W = W;
+  const int pad = ksize / 2;
+  a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+  a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = cin;
+  a.out_cs = out_cs; a.out_coff = out_coff; a.Cout = cout;
+  a.res_cs = res_cs; a.res_coff = res_coff;
+  a.ks = ksize; a.stride = stride; a.relu = relu; a.groups = groups;
+  a.cin8 = (cin + 15) / 16;
+  a.n_tiles = cout <= 32 ? 1 : ((cout + 63) / 64) * 2;
+  a.bias_fstride = bias_frame_stride;
+  a.algo = 0; a.dtype = dtype; a.out_f32 = out_f32 ? 1 : 0;
   hipError_t e = launch_conv(a, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
   return ACRMI_OK;

@@ -126,6 +126,163 @@ hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, h
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit storage variants (f16 / bf16 programs, include/acrmi.h ACRMI_DT_*): the same arithmetic in fp32 on values
+// read from / rounded once (nearest even) to the storage type, 16-byte vectors of 8 elements.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool BF>
+__device__ __forceinline__ void unpack8(const f32x4& v, float (&f)[8]) {
+  if constexpr (BF) {
+    const bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+  } else {
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+  }
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 pack8(const float (&f)[8]) {
+  if constexpr (BF) {
+    bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)f[e];
+    return __builtin_bit_cast(f32x4, h);
+  } else {
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e];
+    return __builtin_bit_cast(f32x4, h);
+  }
+}
+template <bool BF>
+__device__ __forceinline__ unsigned short to16(float f) {
+  if constexpr (BF) return __builtin_bit_cast(unsigned short, (__bf16)f);
+  else return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+template <bool BF>
+__device__ __forceinline__ float from16(unsigned short u) {
+  if constexpr (BF) return (float)__builtin_bit_cast(__bf16, u);
+  else return (float)__builtin_bit_cast(_Float16, u);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void bilinear2x_h16_kernel(const unsigned short* __restrict__ in, int B, int H, int W,
+                                                             int in_cs, int in_coff, int C8, unsigned short* __restrict__ out,
+                                                             int out_cs, int out_coff) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
+  const long n = (long)B * Ho * Wo * C8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c8 = i % C8;
+    long p = i / C8;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const float fy = sh * oy, fx = sw * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const unsigned short* base = in + (size_t)b * H * W * in_cs + in_coff + c8 * 8;
+    float v00[8], v01[8], v10[8], v11[8], r[8];
+    unpack8<BF>(*reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * in_cs), v00);
+    unpack8<BF>(*reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * in_cs), v01);
+    unpack8<BF>(*reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * in_cs), v10);
+    unpack8<BF>(*reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * in_cs), v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_coff + c8 * 8) = pack8<BF>(r);
+  }
+}
+hipError_t launch_bilinear2x_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int C, void* out, int out_cs,
+                                 int out_coff, int dtype, hipStream_t s) {
+  const long n = (long)B * 4 * H * W * (C / 8);
+  auto i16 = reinterpret_cast<const unsigned short*>(in);
+  auto o16 = reinterpret_cast<unsigned short*>(out);
+  if (dtype == 2)
+    hipLaunchKernelGGL(bilinear2x_h16_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, i16, B, H, W, in_cs, in_coff,
+                       C / 8, o16, out_cs, out_coff);
+  else
+    hipLaunchKernelGGL(bilinear2x_h16_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, i16, B, H, W, in_cs, in_coff,
+                       C / 8, o16, out_cs, out_coff);
+  return hipGetLastError();
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void fuse_sum_h16_kernel(const FuseArgs a) {
+  const int C8 = a.C / 8;
+  const long n = (long)a.B * a.H * a.W * C8;
+  unsigned short* out = reinterpret_cast<unsigned short*>(a.out);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c8 = i % C8;
+    long p = i / C8;
+    const int x = p % a.W;
+    p /= a.W;
+    const int y = p % a.H;
+    const int b = p / a.H;
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < a.nterms) {
+        const int sh = a.shift[t];
+        const int h = a.H >> sh, w = a.W >> sh;
+        float v[8];
+        unpack8<BF>(*reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(a.term[t]) +
+                                                    (((size_t)b * h + (y >> sh)) * w + (x >> sh)) * a.cs[t] + c8 * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = t == 0 ? v[e] : acc[e] + v[e];
+      }
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * a.H + y) * a.W + x) * a.out_cs + c8 * 8) = pack8<BF>(acc);
+  }
+}
+// a.term / a.out are 16-bit tensors (pointers carried as float*), strides in elements
+hipError_t launch_fuse_sum_h16(const FuseArgs& a, int dtype, hipStream_t s) {
+  const long n = (long)a.B * a.H * a.W * (a.C / 8);
+  if (dtype == 2) hipLaunchKernelGGL(fuse_sum_h16_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(fuse_sum_h16_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void pow11_h16_kernel(unsigned short* buf, long n_pixels, int cs, int ch) {
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < n_pixels; p += (long)gridDim.x * 256)
+    buf[p * cs + ch] = to16<BF>(powf(1.1f, from16<BF>(buf[p * cs + ch])));
+}
+hipError_t launch_pow11_h16(void* buf, long n_pixels, int cs, int ch, int dtype, hipStream_t s) {
+  auto b16 = reinterpret_cast<unsigned short*>(buf);
+  if (dtype == 2) hipLaunchKernelGGL(pow11_h16_kernel<true>, dim3(grid_for(n_pixels, 256)), dim3(256), 0, s, b16, n_pixels, cs, ch);
+  else hipLaunchKernelGGL(pow11_h16_kernel<false>, dim3(grid_for(n_pixels, 256)), dim3(256), 0, s, b16, n_pixels, cs, ch);
+  return hipGetLastError();
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void coordfill_h16_kernel(unsigned short* buf, int B, int H, int W, int cs, int coff) {
+  const long n = (long)B * H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += (long)gridDim.x * 256) {
+    const int x = p % W, y = (p / W) % H;
+    buf[p * cs + coff] = to16<BF>(((float)x / (float)(W - 1)) * 2.f - 1.f);
+    buf[p * cs + coff + 1] = to16<BF>(((float)y / (float)(H - 1)) * 2.f - 1.f);
+  }
+}
+hipError_t launch_coordfill_h16(void* buf, int B, int H, int W, int cs, int coff, int dtype, hipStream_t s) {
+  auto b16 = reinterpret_cast<unsigned short*>(buf);
+  const int g = grid_for((long)B * H * W, 256);
+  if (dtype == 2) hipLaunchKernelGGL(coordfill_h16_kernel<true>, dim3(g), dim3(256), 0, s, b16, B, H, W, cs, coff);
+  else hipLaunchKernelGGL(coordfill_h16_kernel<false>, dim3(g), dim3(256), 0, s, b16, B, H, W, cs, coff);
+  return hipGetLastError();
+}
+
 }  // namespace acrmi
 
 namespace acrmi {

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void att_stats_kernel(const float* __restrict_
   }
 }
 
-template <int NTILES>
+// FDT = storage type of the feature map (ACRMI_DT_*): 16-bit features (feat then points at 16-bit elements, feat_cs
+// counts them) are widened to fp32 on load; the arithmetic is the fp32 one either way
+template <int NTILES, int FDT = 0>
 __global__ __launch_bounds__(256) void att_pool_kernel(const float* __restrict__ segm, int segm_cs,
                                                        const float* __restrict__ feat, int feat_cs, int H, int W,
                                                        const float* __restrict__ stats, float* __restrict__ part_ws) {
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const float* __restrict__
   const int per_wave = npix / (ATT_KSPLIT * 4);
   const int q0 = (ks * 4 + wave) * per_wave;
   const float* sbase = segm + (size_t)b * (2 * H) * (2 * W) * segm_cs + 1 + li;
-  const float* fbase = feat + (size_t)b * npix * feat_cs + li;
+  const float* fbase = feat + (size_t)b * npix * feat_cs + li;                                  // (fp32 features)
+  const unsigned short* hbase = reinterpret_cast<const unsigned short*>(feat) + (size_t)b * npix * feat_cs + li;
   f32x16 acc[NTILES];
 #pragma unroll
   for (int n = 0; n < NTILES; ++n)
@@ -91,9 +94,18 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const float* __restrict__
     for (int u = 0; u < U; ++u) {
       const int qq = q + 2 * u, y = qq / W, x = qq % W;
       lv[u] = sbase[((size_t)(2 * y) * (2 * W) + 2 * x) * segm_cs];
-      const float* f = fbase + (size_t)qq * feat_cs;
+      if constexpr (FDT == 0) {
+        const float* f = fbase + (size_t)qq * feat_cs;
 #pragma unroll
-      for (int n = 0; n < NTILES; ++n) bv[u][n] = f[n * 32];
+        for (int n = 0; n < NTILES; ++n) bv[u][n] = f[n * 32];
+      } else {
+        const unsigned short* f = hbase + (size_t)qq * feat_cs;
+#pragma unroll
+        for (int n = 0; n < NTILES; ++n) {
+          if constexpr (FDT == 2) bv[u][n] = (float)__builtin_bit_cast(__bf16, f[n * 32]);
+          else bv[u][n] = (float)__builtin_bit_cast(_Float16, f[n * 32]);
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -163,13 +175,21 @@ size_t attpool_ws_floats(int B, int C) {
 }
 
 hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, int H, int W,
-                          float* ws, float* pooled, hipStream_t s) {
+                          float* ws, float* pooled, hipStream_t s, int feat_dtype) {
   const int npix = H * W;
   if (npix % (ATT_KSPLIT * 4 * 8) != 0 || npix % (ATT_SCHUNKS * 32) != 0 || (32 * C) % 256 != 0) return hipErrorInvalidValue;
   float* stats_ws = ws;
   float* part_ws = ws + (size_t)B * ATT_SCHUNKS * 32 * 2;
   hipLaunchKernelGGL(att_stats_kernel, dim3(B, ATT_SCHUNKS), dim3(256), 0, s, segm, segm_cs, H, W, stats_ws);
-  if (C == 320)
+  if (feat_dtype != 0) {   // 16-bit programs pool the 256 contact channels only (the shape conv is folded away)
+    if (C != 256 || feat_dtype < 0 || feat_dtype > 2) return hipErrorInvalidValue;
+    if (feat_dtype == 2)
+      hipLaunchKernelGGL((att_pool_kernel<8, 2>), dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
+                         stats_ws, part_ws);
+    else
+      hipLaunchKernelGGL((att_pool_kernel<8, 1>), dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
+                         stats_ws, part_ws);
+  } else if (C == 320)
     hipLaunchKernelGGL(att_pool_kernel<10>, dim3(B, ATT_KSPLIT), dim3(256), 0, s, segm, segm_cs, feat, feat_cs, H, W,
                        stats_ws, part_ws);
   else if (C == 256)

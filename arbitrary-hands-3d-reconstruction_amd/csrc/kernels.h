@@ -27,6 +27,11 @@ struct ConvArgs {
                         // results), 9 = loader at priority 0; 0 = off
   int xcd_swizzle;      // 1: work items are dealt to the XCDs in contiguous bands (see virtual_block, conv_mfma.hip)
   const float* zeros;   // >= 16 bytes of device zeros (source of halo / pad-channel lanes of conv_wino3's LDS-DMA loader)
+  // Storage type of the activations (ACRMI_DT_*).  F16 / BF16: in, w (and out / res unless out_f32) point at 16-bit
+  // data, channel strides / offsets / counts are in elements of their tensor, cin8 = ceil(Cin / 16), the weights are
+  // packer.pack_conv_h16 fragments and algo must be 0 (conv_h16.hip).
+  int dtype;
+  int out_f32;          // 16-bit input, fp32 output and fp32 residual (the head exits)
 };
 
 // one-time per-DEVICE kernel setup (dynamic LDS attribute): true the first time `flags` (one static array per kernel
@@ -38,6 +43,7 @@ std::recursive_mutex& launch_mutex();
 
 // returns hipSuccess or the launch error; cout tiles etc. derived inside
 hipError_t launch_conv(ConvArgs a, hipStream_t s);
+hipError_t launch_conv_h16(ConvArgs a, hipStream_t s);   // called by launch_conv when a.dtype != ACRMI_DT_F32
 const char* conv_kernel_name(const ConvArgs& a);
 void conv_force_cfg(int cfg);
 void conv_set_debug(long long* dbg);
@@ -49,6 +55,9 @@ hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStrea
 bool stem_shape_ok(int H, int W, int out_cs, int out_coff);
 hipError_t launch_stem(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, float* out,
                        int out_cs, int out_coff, int relu, hipStream_t s);
+// the same with the output rounded to f16 / bf16 (out_cs / out_coff in elements, multiples of 8)
+hipError_t launch_stem_h16(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, void* out,
+                           int out_cs, int out_coff, int relu, int dtype, hipStream_t s);
 hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,
                              int out_cs, int out_coff, hipStream_t s);
 struct FuseArgs {
@@ -62,11 +71,17 @@ hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int
                              uint8_t* out, hipStream_t s);
 hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s);
 hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, hipStream_t s);
+// 16-bit storage variants (dtype = ACRMI_DT_F16 / ACRMI_DT_BF16; strides and offsets in elements, C % 8 == 0)
+hipError_t launch_bilinear2x_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int C, void* out, int out_cs,
+                                 int out_coff, int dtype, hipStream_t s);
+hipError_t launch_fuse_sum_h16(const FuseArgs& a, int dtype, hipStream_t s);   // a.term / a.out carry 16-bit pointers
+hipError_t launch_pow11_h16(void* buf, long n_pixels, int cs, int ch, int dtype, hipStream_t s);
+hipError_t launch_coordfill_h16(void* buf, int B, int H, int W, int cs, int coff, int dtype, hipStream_t s);
 
 // attention pooling: segm [B,2H,2W,segm_cs] logits (channels 1..32 at even pixels), feat [B,H,W,feat_cs] (C ch)
 // stats_ws: [B,32,2] (max, 1/sumexp); pooled [B,32,C]
 hipError_t launch_attpool(const float* segm, int segm_cs, const float* feat, int feat_cs, int C, int B, int H, int W,
-                          float* ws, float* pooled, hipStream_t s);
+                          float* ws, float* pooled, hipStream_t s, int feat_dtype = 0);   // feat may be f16 / bf16 (ACRMI_DT_*)
 size_t attpool_ws_floats(int B, int C);
 
 // pare bias: pooled [B,32,320] -> per-frame bias row [B, biasP] for the 109->109 mix conv

@@ -26,6 +26,12 @@ constexpr int ST_PR = 2 * ST_TH + 1, ST_PC = 2 * ST_TW + 1;       // 17 x 33 inp
 constexpr int ST_ROW = 100;                                       // floats per patch row: 33 * 3 + 1 zero slot
 constexpr int ST_PSTR = 36;
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// DT = ACRMI_DT_*: 0 fp32 output; 1 / 2: the same fp32 result rounded once (nearest even) to f16 / bf16 - `out` then
+// points at 16-bit elements and out_cs / out_coff count them (16-bit programs, include/acrmi.h)
+template <int DT>
 __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                    const float* __restrict__ wpk, const float* __restrict__ bias,
                                                    float* __restrict__ out, int out_cs, int out_coff, int relu) {
@@ -49,9 +55,20 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ i
   for (int s = 0; s < 14; ++s)
 #pragma unroll
     for (int n = 0; n < 2; ++n) wf[s][n] = wpk[(s * 2 + n) * 64 + lane];
-  f32x4 bv[2];
+  // store side: fp32 - lane = (pixel p8 of 8, cout quad q8), 4 rounds per 32-pixel tile; 16-bit - lane = (pixel of 16,
+  // cout octet), 2 rounds
+  const int ps = DT == 0 ? p8 : lane >> 2, qs = DT == 0 ? q8 : lane & 3;
+  f32x4 bv[2][2];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) bv[n] = *reinterpret_cast<const f32x4*>(bias + n * 32 + 4 * q8);
+  for (int n = 0; n < 2; ++n) {
+    if (DT == 0) {
+      bv[n][0] = *reinterpret_cast<const f32x4*>(bias + n * 32 + 4 * q8);
+      bv[n][1] = bv[n][0];
+    } else {
+      bv[n][0] = *reinterpret_cast<const f32x4*>(bias + n * 32 + 8 * qs);
+      bv[n][1] = *reinterpret_cast<const f32x4*>(bias + n * 32 + 8 * qs + 4);
+    }
+  }
   // patch offset of k = 2 s + lh for this lane's pixel (row 2 (2 wave + li / 16) + ky, column (2 (li % 16) + kx) * 3 + c);
   // k = 27 (lh = 1, s = 13) points at the row's zero slot
   int koff[14];
@@ -64,7 +81,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ i
     }
   }
   const uint8_t* frame = img + (size_t)b * H * W * 3;
-  float* outb = out + (size_t)b * Ho * Wo * out_cs + out_coff;
+  float* outb = out + (size_t)b * Ho * Wo * out_cs + out_coff;      // (fp32 output)
+  unsigned short* outh = reinterpret_cast<unsigned short*>(out) + (size_t)b * Ho * Wo * out_cs + out_coff;   // (16-bit)
   const int iy0 = 2 * ty * ST_TH - 1;
   // the patch of strip tile t -> LDS buffer t & 1: element e = r * 99 + j (j = column * 3 + channel).  The bytes are
   // requested before tile t - 1 is computed and converted / written behind it (one HBM latency per tile otherwise)
@@ -121,15 +139,43 @@ __global__ __launch_bounds__(256) void stem_kernel(const uint8_t* __restrict__ i
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(ep + li * ST_PSTR + 8 * q + 4 * lh) =
             f32x4{acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+      if constexpr (DT == 0) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int p = 8 * gq + p8;                       // pixel of the wave's 2 x 16 block
-        f32x4 o4 = *reinterpret_cast<const f32x4*>(ep + p * ST_PSTR + 4 * q8) + bv[n];
-        if (relu) {
-          o4[0] = fmaxf(o4[0], 0.f); o4[1] = fmaxf(o4[1], 0.f); o4[2] = fmaxf(o4[2], 0.f); o4[3] = fmaxf(o4[3], 0.f);
+        for (int gq = 0; gq < 4; ++gq) {
+          const int p = 8 * gq + p8;                       // pixel of the wave's 2 x 16 block
+          f32x4 o4 = *reinterpret_cast<const f32x4*>(ep + p * ST_PSTR + 4 * q8) + bv[n][0];
+          if (relu) {
+            o4[0] = fmaxf(o4[0], 0.f); o4[1] = fmaxf(o4[1], 0.f); o4[2] = fmaxf(o4[2], 0.f); o4[3] = fmaxf(o4[3], 0.f);
+          }
+          const int oy = oy0 + (p >> 4), ox = tx0 + (p & 15);
+          __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(outb + ((size_t)oy * Wo + ox) * out_cs + n * 32 + 4 * q8));
         }
-        const int oy = oy0 + (p >> 4), ox = tx0 + (p & 15);
-        __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(outb + ((size_t)oy * Wo + ox) * out_cs + n * 32 + 4 * q8));
+      } else {
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          const int p = 16 * gq + ps;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + p * ST_PSTR + 8 * qs) + bv[n][0];
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + p * ST_PSTR + 8 * qs + 4) + bv[n][1];
+          float o8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = fmaxf(o8[e], 0.f);
+          }
+          f32x4 pk;
+          if constexpr (DT == 2) {
+            bf16x8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (__bf16)o8[e];
+            pk = __builtin_bit_cast(f32x4, h);
+          } else {
+            f16x8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)o8[e];
+            pk = __builtin_bit_cast(f32x4, h);
+          }
+          const int oy = oy0 + (p >> 4), ox = tx0 + (p & 15);
+          __builtin_nontemporal_store(pk, reinterpret_cast<f32x4*>(outh + ((size_t)oy * Wo + ox) * out_cs + n * 32 + 8 * qs));
+        }
       }
     }
     if (t + 1 < ST_STRIP) stage(t + 1);
@@ -146,7 +192,22 @@ hipError_t launch_stem(const uint8_t* img, int B, int H, int W, const float* wpk
   if (!stem_shape_ok(H, W, out_cs, out_coff) || B <= 0) return hipErrorInvalidValue;
   const long grid = (long)B * (H / 2 / ST_TH) * (W / 2 / (ST_TW * ST_STRIP));
   if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)grid), dim3(256), 0, s, img, H, W, wpk, bias, out, out_cs, out_coff, relu);
+  hipLaunchKernelGGL(stem_kernel<0>, dim3((unsigned)grid), dim3(256), 0, s, img, H, W, wpk, bias, out, out_cs, out_coff, relu);
+  return hipGetLastError();
+}
+
+hipError_t launch_stem_h16(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, void* out,
+                           int out_cs, int out_coff, int relu, int dtype, hipStream_t s) {
+  // (16-byte vectors of 8 elements: strides / offsets are multiples of 8)
+  if (!stem_shape_ok(H, W, out_cs, out_coff) || out_cs % 8 || out_coff % 8 || B <= 0 || (dtype != 1 && dtype != 2))
+    return hipErrorInvalidValue;
+  const long grid = (long)B * (H / 2 / ST_TH) * (W / 2 / (ST_TW * ST_STRIP));
+  if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+  float* o = reinterpret_cast<float*>(out);
+  if (dtype == 2)
+    hipLaunchKernelGGL(stem_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, img, H, W, wpk, bias, o, out_cs, out_coff, relu);
+  else
+    hipLaunchKernelGGL(stem_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, img, H, W, wpk, bias, o, out_cs, out_coff, relu);
   return hipGetLastError();
 }
 

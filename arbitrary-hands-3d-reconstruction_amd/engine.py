@@ -50,10 +50,11 @@ class Engine(object):
             pass
 
     # ---- setup ---------------------------------------------------------------------------------
-    def load_state_dict(self, sd, max_batch=1, keep_taps=False):
+    def load_state_dict(self, sd, max_batch=1, keep_taps=False, precision='fp32', keep_weights=False):
         """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
-        keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`)."""
-        self.load_program(packer.lower(sd, keep_taps=keep_taps), max_batch)
+        keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`).
+        precision: 'fp32' | 'fp16' | 'bf16' (args().model_precision, acr/config.py:96; packer.lower)."""
+        self.load_program(packer.lower(sd, keep_taps=keep_taps, precision=precision, keep_weights=keep_weights), max_batch)
 
     def load_program(self, prog, max_batch=1):
         """A program lowered elsewhere (packer.lower, or another Engine's `program`): the same packed weights and op
@@ -190,14 +191,19 @@ class Engine(object):
         return B
 
     def buffer(self, buf_id, B, channels=None):
-        """Zero-copy torch view [B,h,w,cs] of a program buffer (NHWC)."""
+        """Zero-copy torch view [B,h,w,cs] of a program buffer (NHWC) in its storage type (float32 / float16 /
+        bfloat16: 16-bit programs keep the activations between layers in 16 bits)."""
         h, w, cs = C.c_int(), C.c_int(), C.c_int()
         p = self.L.acrmi_buffer_ptr(self.ctx, buf_id, C.byref(h), C.byref(w), C.byref(cs))
         if not p:
             raise ValueError('no such buffer %d' % buf_id)
+        dt = self.L.acrmi_buffer_dtype(self.ctx, buf_id)
         n = B * h.value * w.value * cs.value
-        arr = _DevArray(p, n, self.device)
-        t = torch.as_tensor(arr, device=self.device).view(B, h.value, w.value, cs.value)
+        arr = _DevArray(p, n, self.device, '<f4' if dt == _lib.DT_F32 else '<i2')
+        t = torch.as_tensor(arr, device=self.device)
+        if dt != _lib.DT_F32:
+            t = t.view(torch.float16 if dt == _lib.DT_F16 else torch.bfloat16)
+        t = t.view(B, h.value, w.value, cs.value)
         return t if channels is None else t[..., :channels]
 
     def head_maps(self, B, nchw=True):
@@ -343,9 +349,9 @@ class EnginePool(object):
         except Exception:
             pass
 
-    def load_state_dict(self, sd, max_batch=1, lanes=1):
+    def load_state_dict(self, sd, max_batch=1, lanes=1, precision='fp32'):
         """sd = None: share the program context 0 already holds."""
-        prog = self.engines[0].program if sd is None else packer.lower(sd)
+        prog = self.engines[0].program if sd is None else packer.lower(sd, precision=precision)
         if prog is None:
             raise _lib.AcrmiError('no checkpoint loaded')
         for e in self.engines:
@@ -416,6 +422,6 @@ class EnginePool(object):
 class _DevArray(object):
     """__cuda_array_interface__ shim so torch can view library-owned HBM without copying."""
 
-    def __init__(self, ptr, n, device):
-        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+    def __init__(self, ptr, n, device, typestr='<f4'):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
         self.device = device

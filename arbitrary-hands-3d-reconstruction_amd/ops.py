@@ -6,7 +6,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .packer import pack_conv, pack_stem, pack_wino3, n_tiles_for, winograd_weights, winograd2d_weights
+from .packer import (DT_BF16, DT_F16, PRECISIONS, pack_conv, pack_conv_h16, pack_stem, pack_wino3, n_tiles_for,
+                     winograd_weights, winograd2d_weights)
 
 
 def _p(t):
@@ -74,6 +75,53 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     _lib.check(L.acrmi_conv2d(_p(x), B, H, W, cs, in_coff, cin, _p(wp), _p(bias_t), fstride, _p(residual),
                               residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1], out_coff,
                               cout, k, stride, int(relu), groups, algo_id, _s(x)))
+    return out
+
+
+def to_nhwc16(x_nchw, precision='fp16', cs=None, device='cuda'):
+    """[B,C,H,W] float (any device) -> contiguous NHWC float16 / bfloat16 on `device`, channel stride cs (a multiple
+    of 8, zero padded): the activation layout of a 16-bit program."""
+    B, Cc, H, W = x_nchw.shape
+    cs = cs or (Cc + 7) // 8 * 8
+    out = torch.zeros(B, H, W, cs, dtype=torch.float16 if precision == 'fp16' else torch.bfloat16, device=device)
+    out[..., :Cc] = x_nchw.permute(0, 2, 3, 1).to(device).to(out.dtype)
+    return out
+
+
+def conv2d_h16(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, cin=None, in_coff=0, out=None,
+               out_coff=0, out_cs=None, frame_bias=None, out_f32=False):
+    """The convolution of a 16-bit program (acrmi_conv2d_h16): x NHWC float16 / bfloat16 [B,H,W,cs] on the device,
+    weight [Cout_total, Cin/groups, k, k] and bias as float arrays (rounded once to x's type by the packer / kept fp32),
+    fp32 accumulation, one rounding of the output.  out_f32: fp32 output and residual (the head exits)."""
+    _need_cuda(x, residual, out, frame_bias)
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError('x must be float16 or bfloat16')
+    dt = DT_F16 if x.dtype == torch.float16 else DT_BF16
+    w = weight.detach().cpu().numpy() if hasattr(weight, 'detach') else np.asarray(weight)
+    cout_t, cin_g, k, _ = w.shape
+    cout = cout_t // groups
+    b = np.zeros(cout_t, np.float32) if bias is None else (
+        bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
+    packed = [pack_conv_h16(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout], dt) for g in range(groups)]
+    wp = torch.from_numpy(np.concatenate([p[0] for p in packed]).view(np.int16)).to(x.device)
+    bp = torch.from_numpy(np.concatenate([p[1] for p in packed])).to(x.device)
+    B, H, W, cs = x.shape
+    cin = cin_g if cin is None else cin
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    odt = torch.float32 if out_f32 else x.dtype
+    if out is None:
+        q = 4 if out_f32 else 8
+        out_cs = out_cs or (cout_t + q - 1) // q * q
+        out = torch.zeros(B, Ho, Wo, out_cs, dtype=odt, device=x.device)
+    if out.dtype != odt or (residual is not None and residual.dtype != odt):
+        raise ValueError('out / residual must be %s' % odt)
+    bias_t, fstride = bp, 0
+    if frame_bias is not None:
+        bias_t, fstride = frame_bias.contiguous().float(), frame_bias.shape[-1]
+    _lib.check(_lib.lib().acrmi_conv2d_h16(_p(x), B, H, W, cs, in_coff, cin, _p(wp), _p(bias_t), fstride, _p(residual),
+                                           residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1],
+                                           out_coff, cout, k, stride, int(relu), groups, dt, int(bool(out_f32)), _s(x)))
     return out
 
 

@@ -10,7 +10,7 @@ activation buffers.  Pure numpy; runs on the host once per checkpoint.
 import numpy as np
 
 from . import _lib
-from .schema import STAGE_CFG, state_dict_schema
+from .schema import stage_cfg, state_dict_schema, width_of
 
 EPS = 1e-5
 # 3x3 stride-1 convolutions run as Winograd F(2,3) along x (exact-arithmetic equivalent, 1.5x fewer MFMAs;
@@ -39,7 +39,7 @@ def strip_prefix(sd, prefix='module.'):
 
 
 def check_state_dict(sd):
-    want = state_dict_schema()
+    want = state_dict_schema(width_of(sd))
     missing = [k for k in want if k not in sd and not k.startswith('segmentation_layers.')
                and not k.endswith('num_batches_tracked')]
     if missing:
@@ -72,6 +72,45 @@ def pack_conv(w, b):
     bp = np.zeros(nt * 32, np.float32)
     bp[:cout] = b
     return np.ascontiguousarray(wp).reshape(-1), bp
+
+
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+PRECISIONS = {'fp32': DT_F32, 'fp16': DT_F16, 'bf16': DT_BF16}
+
+
+def round_to(x, dt):
+    """float64/32 array -> the values of storage type dt (round to nearest even), as float32."""
+    x = np.asarray(x, np.float32)
+    if dt == DT_F16:
+        return x.astype(np.float16).astype(np.float32)
+    if dt == DT_BF16:
+        return (to_bits16(x, dt).astype(np.uint32) << 16).view(np.float32).reshape(x.shape)
+    return x
+
+
+def to_bits16(x, dt):
+    """float array -> uint16 bit patterns of f16 / bf16 (round to nearest even; NaN/Inf never occur in weights)."""
+    x = np.ascontiguousarray(x, np.float32)
+    if dt == DT_F16:
+        return x.astype(np.float16).view(np.uint16)
+    u = x.view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def pack_conv_h16(w, b, dt):
+    """w [Cout,Cin,k,k], b [Cout] -> (packed 16-bit weights as uint16 1-D, padded bias fp32 [n_tiles*32]) for
+    conv_h16_kernel (csrc/conv_h16.inc): the A fragments of v_mfma_f32_32x32x16_{f16,bf16}, 1 KiB each,
+    [tap][s = ci/16][ntile][lane 64][e 8] with cout = ntile*32 + (lane & 31), ci = 16*s + 8*(lane >> 5) + e."""
+    cout, cin, kh, kw = w.shape
+    nt = n_tiles_for(cout)
+    c16 = (cin + 15) // 16
+    wp = np.zeros((nt * 32, c16 * 16, kh, kw), np.float64)
+    wp[:cout, :cin] = w
+    wp = wp.reshape(nt, 32, c16, 2, 8, kh, kw)            # [nt, j, s, h, e, ky, kx]
+    wp = wp.transpose(5, 6, 2, 0, 3, 1, 4)                # [ky, kx, s, nt, h, j, e]
+    bp = np.zeros(nt * 32, np.float32)
+    bp[:cout] = b
+    return to_bits16(np.ascontiguousarray(wp).reshape(-1), dt), bp
 
 
 def pack_wino3(w, b):
@@ -144,6 +183,12 @@ class Blob(object):
         self.parts = [np.zeros(64, np.float32)]   # offset 0 reserved
         self.n = 64
 
+    def add16(self, bits):
+        """uint16 bit patterns (an even number of them) stored in the fp32 blob two per float slot."""
+        bits = np.ascontiguousarray(bits, np.uint16).reshape(-1)
+        assert bits.size % 2 == 0
+        return self.add(bits.view(np.float32))
+
     def add(self, arr):
         arr = np.ascontiguousarray(arr, np.float32).reshape(-1)
         pad = (-arr.size) % 64                     # keep every tensor 256-byte aligned
@@ -161,35 +206,43 @@ class Blob(object):
 class Program(object):
     """Op list + buffer table under construction."""
 
-    def __init__(self, sd):
+    def __init__(self, sd, dt=DT_F32, keep_weights=False):
         self.sd = {k: _np(v) for k, v in sd.items()}
+        self.dt = dt             # storage type of the activations between layers (DT_*); head outputs stay fp32
+        self.keep_weights = keep_weights
         self.blob = Blob()
-        self.bufs = []           # (h, w, cs, persistent)
-        self.free = {}           # (h, w, cs) -> [ids]
+        self.bufs = []           # (h, w, cs, persistent, dtype)
+        self.free = {}           # (h, w, cs, dtype) -> [ids]
         self.ops = []
         self.op_info = []        # python-side description (name, flops) per op
 
     # ---- buffers -----------------------------------------------------------------------------
-    def buf(self, h, w, c, persistent=False):
-        cs = (c + 3) // 4 * 4
-        key = (h, w, cs)
+    def buf(self, h, w, c, persistent=False, f32=False):
+        """f32: an fp32 buffer also in a 16-bit program (head outputs, pooled features, bias rows)."""
+        dt = DT_F32 if f32 else self.dt
+        q = 4 if dt == DT_F32 else 8                     # 16-byte vectors: 4 floats / 8 halfs
+        cs = (c + q - 1) // q * q
+        key = (h, w, cs, dt)
         if not persistent and self.free.get(key):
             return self.free[key].pop()
-        self.bufs.append((h, w, cs, 1 if persistent else 0))
+        self.bufs.append((h, w, cs, 1 if persistent else 0, dt))
         return len(self.bufs) - 1
 
     def release(self, *ids):
         for i in ids:
-            h, w, cs, p = self.bufs[i]
+            h, w, cs, p, dt = self.bufs[i]
             if not p:
-                assert i not in self.free.setdefault((h, w, cs), []), 'double release of buffer %d' % i
-                self.free[(h, w, cs)].append(i)
+                assert i not in self.free.setdefault((h, w, cs, dt), []), 'double release of buffer %d' % i
+                self.free[(h, w, cs, dt)].append(i)
 
     def pin(self, i):
         """Excludes buffer i from lifetime-based reuse from now on (its contents survive the whole program)."""
-        h, w, cs, _ = self.bufs[i]
-        self.bufs[i] = (h, w, cs, 1)
+        h, w, cs, _, dt = self.bufs[i]
+        self.bufs[i] = (h, w, cs, 1, dt)
         return i
+
+    def dtype_of(self, i):
+        return self.bufs[i][4]
 
     def dims(self, i):
         return self.bufs[i][:3]
@@ -253,13 +306,23 @@ class Program(object):
             wb_list, cout = [(wp, bp)], 32
         if out is None:
             out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
-        algo = conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None)
-        if algo == 3:
-            packed = [pack_wino3(w, b) for (w, b) in wb_list]
+        if self.dt != DT_F32:
+            # 16-bit program: every conv is the direct f16 / bf16 MFMA kernel (the matrix pipe is 16x faster than
+            # in fp32 and the layers are HBM-bound: Winograd would only add arithmetic error).  A residual has the
+            # type of the output (16-bit between layers, fp32 where a head map accumulates in place).
+            assert self.dtype_of(src) == self.dt, 'conv input must be a 16-bit buffer in a 16-bit program'
+            assert res is None or self.dtype_of(res) == self.dtype_of(out)
+            algo = 0
+            packed = [pack_conv_h16(w, b, self.dt) for (w, b) in wb_list]
+            w_off = self.blob.add16(np.concatenate([p[0] for p in packed]))
         else:
-            tr = (lambda t: t, winograd_weights, winograd2d_weights)[algo]
-            packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
-        w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
+            algo = conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None)
+            if algo == 3:
+                packed = [pack_wino3(w, b) for (w, b) in wb_list]
+            else:
+                tr = (lambda t: t, winograd_weights, winograd2d_weights)[algo]
+                packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
+            w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
         flops = 2.0 * ho * wo * flop_cout * cin_w * k * k * len(wb_list)     # algorithmic (direct-conv) FLOPs
         self._op(name, flops, kind=_lib.OP_CONV, in_buf=src, out_buf=out, res_buf=-1 if res is None else res,
@@ -267,6 +330,8 @@ class Program(object):
                  relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=algo,
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds')[algo]
+        if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
+            self.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for (w, b) in wb_list]
         return out
 
     def conv_bn(self, src, conv, bn, k, stride, relu, **kw):
@@ -372,15 +437,30 @@ def point_tower(P, side, k):
     return out
 
 
-def lower(sd, check=True, point_heads=True, keep_taps=False):
-    """state dict -> dict(blob, bufs, ops, heads, op_info, taps).  See module docstring.
-    point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT).
+def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False):
+    """state dict -> dict(blob, bufs, ops, heads, op_info, taps, precision, width).  See module docstring.
+    point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT; fp32 W32 only).
     keep_taps: pin the buffers of the backbone taps the golden vectors hold (stem / layer1 / stage2 / stage3 branch 0,
-    tests/golden/make_golden.py) so a test can read them after the run; costs ~0.6 GB at batch 64, off by default."""
+    tests/golden/make_golden.py) so a test can read them after the run; costs ~0.6 GB at batch 64, off by default.
+    precision: 'fp32' (the reference's configs/demo.yml), or 'fp16' / 'bf16' = the reference's autocast branch
+    (acr/model.py:33-37, --model_precision fp16) re-stated for gfx950: activations between layers are stored in 16
+    bits (NHWC, channel stride a multiple of 8), weights are the BN-folded filters rounded once to 16 bits, every
+    conv accumulates in fp32 on v_mfma_f32_32x32x16_{f16,bf16} and applies bias / residual / ReLU in fp32 before the one
+    rounding of its output; the stem conv (K = 27, reads uint8), the exits of the head towers (center, params x mix,
+    prior, segm logits), attention pooling, pare bias, decode and MANO stay fp32 (the reference's .float() at
+    acr/model.py:56-62).  The HRNet width (32 / 48) is read off the checkpoint.
+    keep_weights: op_info[i]['wb'] keeps the folded fp64 filters of every conv (oracle/program.py, tests only)."""
     sd = strip_prefix(sd)
     if check:
         check_state_dict(sd)
-    P = Program(sd)
+    if precision not in PRECISIONS:
+        raise ValueError('precision %r: one of %s' % (precision, sorted(PRECISIONS)))
+    width = width_of({k: _np(v) for k, v in sd.items() if k == 'backbone.transition1.0.0.weight'})
+    STAGE_CFG = stage_cfg(width)
+    c0 = width
+    dt = PRECISIONS[precision]
+    point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
+    P = Program(sd, dt, keep_weights)
     b = 'backbone.'
     # ---- stem -----------------------------------------------------------------------------------
     w, bb = P.folded(b + 'conv1', b + 'bn1')
@@ -390,6 +470,8 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
         P._op(b + 'conv1', 2.0 * 256 * 256 * 64 * 3 * 9, kind=_lib.OP_STEM, out_buf=x, cin=3, cout=64, ksize=3, stride=2,
               relu=1, groups=1, w_off=P.blob.add(wp), b_off=P.blob.add(bp))
         P.op_info[-1]['algo'] = 'stem_u8'
+        if keep_weights:
+            P.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(bb, np.float64))]
     else:
         x0 = P.buf(512, 512, 4)
         P._op('u8norm', 0.0, kind=_lib.OP_U8NORM, out_buf=x0)
@@ -410,8 +492,8 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
     t = b + 'transition1'
     xs = [P.conv_bn(x, t + '.0.0', t + '.0.1', 3, 1, True), P.conv_bn(x, t + '.1.0.0', t + '.1.0.1', 3, 2, True)]
     P.release(x)
-    x34 = P.buf(128, 128, 34, persistent=True)      # backbone output (32) + coord maps (2), acr/model.py:52
-    P._op('coordfill', 0.0, kind=_lib.OP_COORDFILL, out_buf=x34, out_coff=32)
+    x34 = P.buf(128, 128, c0 + 2, persistent=True)      # backbone output (32) + coord maps (2), acr/model.py:52
+    P._op('coordfill', 0.0, kind=_lib.OP_COORDFILL, out_buf=x34, out_coff=c0)
     for s in (2, 3, 4):
         ch = STAGE_CFG[s]['channels']
         if s > 2:
@@ -428,15 +510,15 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
     # ---- part-segmentation head (acr/model.py:374-463) ------------------------------------------
     u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
     g = b + 'hand_segm.segm_head.segm_net.double_conv'
-    up = P.buf(256, 256, 32)
-    P._op('segm.bilinear2x', 0.0, kind=_lib.OP_BILINEAR2X, in_buf=x34, out_buf=up, cin=32)
+    up = P.buf(256, 256, c0)
+    P._op('segm.bilinear2x', 0.0, kind=_lib.OP_BILINEAR2X, in_buf=x34, out_buf=up, cin=c0)
     s1 = P.conv_bn(up, u + '.0', u + '.1', 3, 1, True)
     P.release(up)
     s2 = P.conv_bn(s1, u + '.3', u + '.4', 3, 1, True)
     P.release(s1)
     s3 = P.conv_bn(s2, g + '.0', g + '.1', 3, 1, True)
     P.release(s2)
-    segm = P.buf(256, 256, 33, persistent=True)
+    segm = P.buf(256, 256, 33, persistent=True, f32=True)
     P.conv(g + '.3', s3, [P.folded(g + '.3')], 3, 1, False, out=segm)
     P.release(s3)
     # ---- 8 head towers (acr/model.py:71-92, 288-313), batched as one 34->512 conv + grouped blocks --
@@ -447,11 +529,11 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
     wcat = np.concatenate([w for w, _ in w_list], 0)
     bcat = np.concatenate([bb for _, bb in w_list], 0)
     n0 = len(P.ops)
-    t0 = P.conv('towers.entry', x34, [(wcat, bcat)], 3, 2, True, cin=34)
+    t0 = P.conv('towers.entry', x34, [(wcat, bcat)], 3, 2, True, cin=c0 + 2)
     P.set_mode(_lib.MODE_DENSE, n0)
     if point_heads:
         n0 = len(P.ops)
-        P.conv('towers.entry.centers', x34, [(wcat[:128], bcat[:128])], 3, 2, True, cin=34, out=t0)
+        P.conv('towers.entry.centers', x34, [(wcat[:128], bcat[:128])], 3, 2, True, cin=c0 + 2, out=t0)
         P.set_mode(_lib.MODE_POINT, n0)
     for k in range(2):
         c1 = [P.folded('%s_final_layers.%d.1.%d.0.conv1' % (s_, t_, k), '%s_final_layers.%d.1.%d.0.bn1' % (s_, t_, k))
@@ -491,11 +573,11 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
         wa = wm[:, :109].copy()
         wa[:, :3] += wm[:, 109:112]                 # cam3 appears twice in the concat (acr/model.py:160-163)
         mix_w[side] = (wa, wm[:, 112:])
-        p109[side] = P.buf(64, 64, 109)              # point heads: raw exits of the sampled pixel
-        final[side] = P.buf(64, 64, 128, persistent=True)
+        p109[side] = P.buf(64, 64, 109, f32=True) if point_heads else -1   # point heads: raw exits of the sampled pixel
+        final[side] = P.buf(64, 64, 128, persistent=True, f32=True)
         camb[side] = P.buf(64, 64, 32)
-        center = P.buf(64, 64, 32, persistent=True)
-        prior = P.buf(64, 64, 128, persistent=True)
+        center = P.buf(64, 64, 32, persistent=True, f32=True)
+        prior = P.buf(64, 64, 128, persistent=True, f32=True)
         name = '%s_final_layers.%%d.2' % side
         tin = lambda k: 64 * towers.index((side, k))
         P.conv(name % 2, t0, [padded(*P.folded(name % 2), 32)], 1, 1, False, out=center, in_coff=tin(2), cin=64)
@@ -520,8 +602,8 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
     # folded into the Linear that consumes it (cam_shape_layers.2/3) below; the 256->64 conv over the 128x128 map and
     # 64 of the 320 pooled channels disappear.
     feat = P.buf(128, 128, 256)
-    P.conv('contact_layers.1.0', x34, [P.folded('contact_layers.1.0', 'contact_layers.1.1')], 3, 1, True, out=feat, cin=34)
-    pooled = P.buf(1, 32, 256)
+    P.conv('contact_layers.1.0', x34, [P.folded('contact_layers.1.0', 'contact_layers.1.1')], 3, 1, True, out=feat, cin=c0 + 2)
+    pooled = P.buf(1, 32, 256, f32=True)
     P._op('attpool', 2.0 * 32 * 16384 * 320 + 2.0 * 128 * 128 * 256 * 64, kind=_lib.OP_ATTPOOL, in_buf=segm, res_buf=feat,
           out_buf=pooled, cin=256)
     P.op_info[-1]['name'] = 'attpool(+cam_shape_layers.1.0)'
@@ -530,7 +612,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
     wcs = wcs[:, :, 0, 0]                                # [64, 256]
     for si, (side, lc, mix, part0) in enumerate((('l', 2, 4, 16), ('r', 3, 5, 0))):
         wa, wp = mix_w[side]
-        bias_buf = P.buf(1, 1, 128, persistent=True)     # one per side: acrmi_point_heads re-reads both
+        bias_buf = P.buf(1, 1, 128, persistent=True, f32=True)     # one per side: acrmi_point_heads re-reads both
         lw = _np(sd['cam_shape_layers.%d.weight' % lc]).astype(np.float64).reshape(10, 64, 16)    # [k, c, j]
         lin_w = np.einsum('kcj,cd->kdj', lw, wcs).reshape(10, 256 * 16)                            # [k, c' * 16 + j]
         lin_b = _np(sd['cam_shape_layers.%d.bias' % lc]).astype(np.float64) + np.einsum('kcj,c->k', lw, bcs)
@@ -553,4 +635,5 @@ def lower(sd, check=True, point_heads=True, keep_taps=False):
                   w_off2=P.blob.add(mixw))
         heads.params_buf[si] = final[side]
     heads.segm_buf, heads.backbone_buf = segm, x34
-    return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info, 'taps': taps}
+    return {'blob': P.blob.finish(), 'bufs': P.bufs, 'ops': P.ops, 'heads': heads, 'op_info': P.op_info, 'taps': taps,
+            'precision': precision, 'width': width}

@@ -1,4 +1,6 @@
-"""Checkpoint schema of the ACR network (HRNet-W32 + ACR heads).
+"""Checkpoint schema of the ACR network (HRNet-W32 + ACR heads; `width` = 48 gives the HRNet-W48 variant that
+BASELINE.json configs[4] names - the reference itself hard-wires W32, acr/model.py:797-819, so W48 is build-defined:
+branch widths 48/96/192/384, heads fed by 48 + 2 coordinate channels, everything else unchanged).
 
 This enumerates, from the topology alone, every tensor of the reference's
 ``acr.model.ACR().state_dict()`` (names, shapes, role), so that the packer,
@@ -13,11 +15,19 @@ from the imported reference (tests/golden/schema_digest.json).
 """
 from collections import OrderedDict
 
-STAGE_CFG = {
-    2: dict(modules=1, channels=[32, 64]),
-    3: dict(modules=4, channels=[32, 64, 128]),
-    4: dict(modules=3, channels=[32, 64, 128, 256]),
-}
+def stage_cfg(width=32):
+    """acr/model.py:797-819 (stage2/3/4_cfg) with NUM_CHANNELS scaled to `width`."""
+    w = int(width)
+    if w not in (32, 48):
+        raise ValueError('HRNet width %r: 32 (the reference) and 48 (BASELINE.json configs[4]) are defined' % (width,))
+    return {
+        2: dict(modules=1, channels=[w, 2 * w]),
+        3: dict(modules=4, channels=[w, 2 * w, 4 * w]),
+        4: dict(modules=3, channels=[w, 2 * w, 4 * w, 8 * w]),
+    }
+
+
+STAGE_CFG = stage_cfg(32)
 BLOCKS_PER_BRANCH = 4
 HEAD_CHANNELS = 64
 HEAD_BLOCKS = 2
@@ -49,8 +59,16 @@ def fuse_plan(nb, multi_scale):
     return [(i, j) for i in range(nb if multi_scale else 1) for j in range(nb) if j != i]
 
 
-def state_dict_schema():
+def width_of(sd):
+    """HRNet width of a checkpoint (bare keys): the channel count of branch 0."""
+    w = sd.get('backbone.transition1.0.0.weight')
+    return 32 if w is None else int(w.shape[0])
+
+
+def state_dict_schema(width=32):
     """OrderedDict key -> shape, in the reference's registration order."""
+    STAGE_CFG = stage_cfg(width)
+    c0 = STAGE_CFG[2]['channels'][0]
     d = OrderedDict()
     b = 'backbone.'
     _conv(d, b + 'conv1', 64, 3, 3, False); _bn(d, b + 'bn1', 64)
@@ -99,7 +117,7 @@ def state_dict_schema():
         pre = ch
     # part-segmentation head (acr/model.py:374-463)
     u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
-    _conv(d, u + '.0', 16, 32, 3, True); _bn(d, u + '.1', 16)
+    _conv(d, u + '.0', 16, c0, 3, True); _bn(d, u + '.1', 16)
     _conv(d, u + '.3', 64, 16, 3, True); _bn(d, u + '.4', 64)
     g = b + 'hand_segm.segm_head.segm_net.double_conv'
     _conv(d, g + '.0', 33, 64, 3, True); _bn(d, g + '.1', 33)
@@ -108,11 +126,11 @@ def state_dict_schema():
     for side in ('l', 'r'):
         for t in (1, 2, 3, 4):
             p = '%s_final_layers.%d' % (side, t)
-            _conv(d, p + '.0.0', HEAD_CHANNELS, 34, 3, True); _bn(d, p + '.0.1', HEAD_CHANNELS)
+            _conv(d, p + '.0.0', HEAD_CHANNELS, c0 + 2, 3, True); _bn(d, p + '.0.1', HEAD_CHANNELS)
             for k in range(HEAD_BLOCKS):
                 _basic_block(d, p + '.1.%d.0' % k, HEAD_CHANNELS)
             _conv(d, p + '.2', TOWER_OUT[t], HEAD_CHANNELS, 1, True)
-    _conv(d, 'contact_layers.1.0', 256, 34, 3, True); _bn(d, 'contact_layers.1.1', 256)
+    _conv(d, 'contact_layers.1.0', 256, c0 + 2, 3, True); _bn(d, 'contact_layers.1.1', 256)
     d['contact_layers.2.weight'] = (1, 6, 256, 16, 1, 1)
     d['contact_layers.3.weight'] = (1, 6, 256, 16, 1, 1)
     _conv(d, 'contact_layers.4', PARAMS_NUM, 2 * PARAMS_NUM, 1, True)
@@ -122,15 +140,15 @@ def state_dict_schema():
         d['cam_shape_layers.%d.weight' % k] = (10, 1024)
         d['cam_shape_layers.%d.bias' % k] = (10,)
     # built by the reference but never called (acr/model.py:181,262-286); still in checkpoints
-    _conv(d, 'segmentation_layers.1.0', 256, 34, 3, True); _bn(d, 'segmentation_layers.1.1', 256)
+    _conv(d, 'segmentation_layers.1.0', 256, c0 + 2, 3, True); _bn(d, 'segmentation_layers.1.1', 256)
     _conv(d, 'segmentation_layers.2.0', 33, 256, 1, True)
     return d
 
 
-def schema_digest():
+def schema_digest(width=32):
     import hashlib
     h = hashlib.sha256()
-    d = state_dict_schema()
+    d = state_dict_schema(width)
     for k, s in d.items():
         h.update(('%s:%s;' % (k, ','.join(map(str, s)))).encode())
     n_params = 0

@@ -17,22 +17,27 @@ from .schema import state_dict_schema
 _LAST_BN_SUFFIX = ('.bn2.weight', '.bn3.weight')
 
 
-def make_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefix=''):
+def make_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefix='', width=32, law='benign'):
     """Returns an OrderedDict key -> float32 array (torch tensors if as_torch).
 
     center_bias: (left, right) bias of the 64->1 center-tower exit conv; use a
     large negative value to suppress detections of that hand.
+    width: HRNet width (32 = the reference's network; 48 = BASELINE.json configs[4], schema.stage_cfg).
+    law: 'benign' (above) or 'hostile' (make_hostile_state_dict: trained-like BatchNorm statistics).
     """
+    if law == 'hostile':
+        return make_hostile_state_dict(seed, center_bias, as_torch, prefix, width)
     rng = np.random.Generator(np.random.PCG64(seed))
     out = {}
-    for key, shape in state_dict_schema().items():
+    sch = state_dict_schema(width)
+    for key, shape in sch.items():
         if key.endswith('num_batches_tracked'):
             v = np.array(1000, dtype=np.int64)
         elif key.endswith('running_mean'):
             v = rng.normal(0.0, 0.1, shape)
         elif key.endswith('running_var'):
             v = rng.uniform(0.8, 1.2, shape)
-        elif _is_bn(key):
+        elif _is_bn(key, sch):
             if key.endswith('.weight'):
                 if key.endswith(_LAST_BN_SUFFIX):
                     lo, hi = 0.15, 0.3
@@ -60,28 +65,113 @@ def make_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefix=''):
         # keep cam scale/params in a sane range: small exit weights for cam and params towers
         for t in (1, 3, 4):
             out[prefix + '%s_final_layers.%d.2.weight' % (side, t)] *= 0.3
-    if as_torch:
-        import torch
-        out = {k: (torch.tensor(int(v)) if v.ndim == 0 else torch.from_numpy(np.ascontiguousarray(v)))
-               for k, v in out.items()}
-    return out
+    return _as_torch(out) if as_torch else out
 
 
-def _is_bn(key):
+def _as_torch(out):
+    import torch
+    return {k: (torch.tensor(int(v)) if v.ndim == 0 else torch.from_numpy(np.ascontiguousarray(v)))
+            for k, v in out.items()}
+
+
+BN_EPS = 1e-5
+
+
+def make_hostile_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefix='', width=32, stream_scale=50.0,
+                            row_decades=(-1.5, 1.0), chan_decades=(-1.0, 1.0)):
+    """The benign checkpoint of the same seed re-parametrised into trained-like statistics WITHOUT changing the
+    function it computes (in exact arithmetic), so that the benign checkpoint's reference outputs stay the ground truth
+    and every difference is fp32 / Winograd round-off of the implementation under test:
+
+      * raw conv rows: every conv that feeds a BatchNorm has output channel c scaled by s_c = 10**U(row_decades), its
+        BatchNorm's running_mean by s_c and running_var' = (var + eps) s_c**2 - eps: running_var spans 1e-3 .. 1e2,
+        the raw weights span 2.5 decades per layer, the folded weights are unchanged up to rounding;
+      * block-internal activations: the BatchNorm inside a BasicBlock / Bottleneck / plain conv chain gets
+        (gamma, beta)_c *= f_c = 10**U(chan_decades) and the only consumer's input-channel weights /= f_c: the inputs of
+        the Winograd convs (conv2 of every block) have per-channel magnitudes over two decades and gamma outliers;
+      * residual stream of the backbone: every BatchNorm that writes the stream gets (gamma, beta) *= stream_scale and
+        every conv that reads it has its weights /= stream_scale: activations of O(stream_scale) (up to ~1e2) wherever
+        the fp32 path adds residuals, fuses branches or feeds a head.
+    The re-parametrisation is done in float64 and rounded once to float32."""
+    sd = make_state_dict(seed, center_bias, as_torch=False, prefix='', width=width)
+    sch = state_dict_schema(width)
+    c0 = width
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    d = {k: (v.astype(np.float64) if v.dtype != np.int64 else v) for k, v in sd.items()}
+
+    def bn_of(conv):
+        """BatchNorm that follows conv `name` (by the reference's naming), or None."""
+        base, leaf = conv.rsplit('.', 1)
+        cands = []
+        if leaf.startswith('conv'):
+            cands.append(base + '.bn' + leaf[4:])
+        if leaf.isdigit():
+            cands.append(base + '.' + str(int(leaf) + 1))
+        for c in cands:
+            if (c + '.running_mean') in sch:
+                return c
+        return None
+
+    convs = [k[:-7] for k, shp in sch.items() if k.endswith('.weight') and len(shp) == 4]
+    pairs = [(c, bn_of(c)) for c in convs if bn_of(c) is not None and not c.startswith('segmentation_layers')]
+    # ---- (1) raw row scales ------------------------------------------------------------------------
+    for conv, bn in pairs:
+        n = d[conv + '.weight'].shape[0]
+        s = 10.0 ** rng.uniform(row_decades[0], row_decades[1], n)
+        d[conv + '.weight'] *= s[:, None, None, None]
+        if (conv + '.bias') in d:
+            d[conv + '.bias'] *= s
+        d[bn + '.running_mean'] *= s
+        d[bn + '.running_var'] = (d[bn + '.running_var'] + BN_EPS) * s * s - BN_EPS
+    # ---- (2) block-internal channel scales: (bn, the one conv that consumes its output) ------------
+    internal = [('backbone.bn1', 'backbone.conv2')]
+    for k in sch:
+        if k.endswith('.conv2.weight'):
+            p = k[:-len('.conv2.weight')]
+            internal.append((p + '.bn1', p + '.conv2'))
+            if (p + '.conv3.weight') in sch:
+                internal.append((p + '.bn2', p + '.conv3'))
+    u = 'backbone.hand_segm.segm_head.upsampler.up1.conv.double_conv'
+    g = 'backbone.hand_segm.segm_head.segm_net.double_conv'
+    internal += [(u + '.1', u + '.3'), (u + '.4', g + '.0'), (g + '.1', g + '.3')]
+    for bn, consumer in internal:
+        n = d[bn + '.weight'].shape[0]
+        f = 10.0 ** rng.uniform(chan_decades[0], chan_decades[1], n)
+        d[bn + '.weight'] *= f
+        d[bn + '.bias'] *= f
+        d[consumer + '.weight'] /= f[None, :, None, None]
+    # ---- (3) backbone residual stream -------------------------------------------------------------
+    S = float(stream_scale)
+    writers, readers = ['backbone.bn2'], []
+    for k in sch:
+        if not k.startswith('backbone.') or not k.endswith('.weight') or len(sch[k]) != 4:
+            continue
+        c = k[:-7]
+        if '.layer1.' in c or '.branches.' in c:
+            if c.endswith('.conv1') or c.endswith('.downsample.0'):
+                readers.append(c)
+            last = '.conv3' if '.layer1.' in c else '.conv2'
+            if c.endswith(last) or c.endswith('.downsample.0'):
+                writers.append(bn_of(c))
+        elif '.transition' in c or '.fuse_layers.' in c:
+            readers.append(c)
+            writers.append(bn_of(c))
+    readers.append(u + '.0')
+    for bn in writers:
+        d[bn + '.weight'] *= S
+        d[bn + '.bias'] *= S
+    for c in readers:
+        d[c + '.weight'] /= S
+    for c in ['%s_final_layers.%d.0.0' % (s_, t) for s_ in 'lr' for t in (1, 2, 3, 4)] + ['contact_layers.1.0']:
+        d[c + '.weight'][:, :c0] /= S        # the two coordinate channels are not part of the stream
+    out = {prefix + k: (v if v.dtype == np.int64 else v.astype(np.float32)) for k, v in d.items()}
+    return _as_torch(out) if as_torch else out
+
+
+def _is_bn(key, sch):
     """True for BatchNorm weight/bias tensors (their module also owns a running_mean)."""
-    sch = _schema_cache()
     base = key.rsplit('.', 1)[0]
     return (base + '.running_mean') in sch
-
-
-_SCH = None
-
-
-def _schema_cache():
-    global _SCH
-    if _SCH is None:
-        _SCH = state_dict_schema()
-    return _SCH
 
 
 KINTREE_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ACRMI_VERSION 200
+#define ACRMI_VERSION 300
 
 #define ACRMI_OK 0
 #define ACRMI_EINVAL (-1)  /* bad argument / unsupported shape  (reference: ValueError / assert) */
@@ -37,12 +37,20 @@ typedef struct acrmi_ctx acrmi_ctx;
  * Program description.  The Python host (packer.py) folds BatchNorm into the conv weights,
  * packs them in the MFMA fragment order, and lowers the network topology
  * (acr/model.py:785-865 backbone, :47-166 heads) into a flat op list over numbered
- * activation buffers (NHWC fp32, channel stride = cs floats).  The library owns the
- * buffers and replays the list; it knows nothing about HRNet.
+ * activation buffers (NHWC, channel stride = cs elements; fp32, or f16 / bf16 between the layers of
+ * a 16-bit program).  The library owns the buffers and replays the list; it knows nothing about HRNet.
  * ------------------------------------------------------------------------------------- */
+/* Storage type of an activation buffer.  An fp32 program (the reference's configs/demo.yml, model_precision fp32) uses
+ * ACRMI_DT_F32 everywhere.  A 16-bit program (the reference's autocast branch, acr/model.py:33-37, --model_precision
+ * fp16; bf16 is the same program with the other 16-bit type) stores the activations BETWEEN layers as f16 / bf16, keeps
+ * fp32 accumulation and fp32 bias / residual / ReLU arithmetic inside every kernel, and keeps the head outputs (center,
+ * params, prior, segm maps), the pooled part features and everything behind them in fp32 (acr/model.py:56-62 .float()). */
+enum { ACRMI_DT_F32 = 0, ACRMI_DT_F16 = 1, ACRMI_DT_BF16 = 2 };
+
 typedef struct {
-  int32_t h, w, cs;      /* per-frame height, width, channel stride (floats, multiple of 4) */
+  int32_t h, w, cs;      /* per-frame height, width, channel stride in ELEMENTS (a multiple of 16 bytes) */
   int32_t persistent;    /* 1: never aliased with another buffer (holds init-time constants) */
+  int32_t dtype;         /* ACRMI_DT_*; all 16-bit buffers of a program share one type */
 } acrmi_buffer_desc;
 
 enum {
@@ -138,8 +146,10 @@ int acrmi_load_mano(acrmi_ctx* ctx, int side, const float* v_template, const flo
  * program's head buffers (see acrmi_buffer_ptr). */
 int acrmi_backbone_heads(acrmi_ctx* ctx, const uint8_t* img_dev, int B, void* stream);
 
-/* Device pointer / geometry of program buffer `buf` (valid until the next set_program). */
+/* Device pointer / geometry of program buffer `buf` (valid until the next set_program); cs counts elements of
+ * acrmi_buffer_dtype(ctx, buf) (ACRMI_DT_*, -1 for an unknown buffer). */
 void* acrmi_buffer_ptr(acrmi_ctx* ctx, int buf, int* h, int* w, int* cs);
+int acrmi_buffer_dtype(acrmi_ctx* ctx, int buf);
 
 /* acr/result_parser.py:21-40,85-190 (ResultParser.parse/parse_maps) + acr/utils.py:334-382
  * (6D -> axis-angle), per-frame semantics: slots_dev [B,2,ACRMI_SLOT]. */
@@ -187,6 +197,16 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,
                  int algo, void* stream);
+/* The convolution of a 16-bit program (acr/model.py:33-37, the autocast branch): in / res / out point at f16 (dtype =
+ * ACRMI_DT_F16) or bf16 (ACRMI_DT_BF16) NHWC tensors, strides / offsets / channel counts in elements (strides multiples
+ * of 8), w_packed = packer.pack_conv_h16(w, b, dtype) (BN-folded filters rounded once to the storage type, A fragments
+ * of v_mfma_f32_32x32x16_{f16,bf16}), bias fp32.  fp32 accumulation; bias, residual and ReLU in fp32; ONE rounding of
+ * the result.  out_f32 != 0: out AND res are fp32 tensors (strides multiples of 4; stride-1 shapes only) - the head
+ * exits, whose maps the reference converts with .float() (acr/model.py:56-62). */
+int acrmi_conv2d_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int cin, const void* w_packed,
+                     const float* bias, int bias_frame_stride, const void* res, int res_cs, int res_coff, void* out,
+                     int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups, int dtype,
+                     int out_f32, void* stream);
 /* acr/utils.py:1276-1337 (img_preprocess / image_pad_white_bg / cv2.resize INTER_CUBIC): n BGR uint8 frames
  * [n,H,W,3] on the device -> RGB uint8 [n,512,512,3]: white pad to square (imgaug 0.4.0
  * compute_paddings_to_reach_aspect_ratio + Pad), then OpenCV's uint8 INTER_CUBIC restated bit for bit (a = -0.75,
