@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get('ACRMI_LIB') or os.path.join(HERE, 'libacrmi.so')   # 
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
-OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF = 1, 2, 3, 4, 5, 6
+OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF, OPT_MANO_FP16 = 1, 2, 3, 4, 5, 6, 7
 VERSION = 300
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SLOT = 176

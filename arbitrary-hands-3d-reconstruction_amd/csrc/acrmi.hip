@@ -54,7 +54,8 @@ struct acrmi_ctx {
   std::vector<hipEvent_t> op_ev;
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
-  float* mano_allocs[2][6] = {};
+  float* mano_allocs[2][9] = {};   // 6 fp32 tables + 3 f16 copies per side
+  bool mano_f16 = false;           // ACRMI_OPT_MANO_FP16
   // options the reference reads from its config (acr/config.py): centermap_conf_thresh (acr/result_parser.py:241),
   // align_idx / mano_mesh_root_align (acr/mano_wrapper.py:19-33), -t temporal_optimization + smooth_coeff (acr/main.py:45-47)
   float conf_thresh = 0.35f;
@@ -602,6 +603,23 @@ int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float
   if ((r = up(J_regressor, 16 * 778, &t.jreg))) return r;
   if ((r = up(weights, 778 * 16, &t.weights))) return r;
   if ((r = up(hands_mean, 45, &t.hands_mean))) return r;
+  // f16 copies of the blend-shape tables and the skinning weights (ACRMI_OPT_MANO_FP16), rounded to nearest even
+  auto up16 = [&](const float* h, size_t n, const unsigned short** dst) -> int {
+    std::vector<unsigned short> bits(n + (n & 1));
+    for (size_t i = 0; i < n; ++i) {
+      const _Float16 v = (_Float16)h[i];
+      memcpy(&bits[i], &v, 2);
+    }
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, bits.size() * 2));
+    c->mano_allocs[side][n_up++] = d;
+    HIPCHK(c, hipMemcpy(d, bits.data(), bits.size() * 2, hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<const unsigned short*>(d);
+    return ACRMI_OK;
+  };
+  if ((r = up16(sd_t.data(), sd_t.size(), &t.shapedirs_h))) return r;
+  if ((r = up16(pd_t.data(), pd_t.size(), &t.posedirs_h))) return r;
+  if ((r = up16(weights, 778 * 16, &t.weights_h))) return r;
   c->have_mano[side] = true;
   return ACRMI_OK;
 }
@@ -701,6 +719,10 @@ int acrmi_set_option(acrmi_ctx* c, int option, int value) {
   }
   if (option == ACRMI_OPT_TEMPORAL) {
     c->temporal = value != 0;
+    return ACRMI_OK;
+  }
+  if (option == ACRMI_OPT_MANO_FP16) {
+    c->mano_f16 = value != 0;
     return ACRMI_OK;
   }
   return fail(c, ACRMI_EINVAL, "acrmi_set_option: unknown option %d", option);
@@ -846,6 +868,7 @@ int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* b
   m.verts = verts; m.joints = joints; m.center = center;
   m.cam = cam; m.cam_stride = cam_stride; m.offsets = offsets; m.off_div = 1;
   m.verts_camed = verts_camed; m.pj2d = pj2d; m.pj2d_org = pj2d_org;
+  m.lbs_f16 = c->mano_f16;
   HIPCHK(c, launch_mano(m, (hipStream_t)stream));
   return ACRMI_OK;
 }
@@ -866,6 +889,7 @@ static int forward_tail(acrmi_ctx* c, int B, const float* offsets, float* slots,
   m.cam = proj ? slots + ACRMI_SLOT_CAM : nullptr; m.cam_stride = ACRMI_SLOT;
   m.offsets = offsets; m.off_div = 2;
   m.verts_camed = verts_camed; m.pj2d = pj2d; m.pj2d_org = pj2d_org;
+  m.lbs_f16 = c->mano_f16;
   HIPCHK(c, launch_mano(m, stream));
   return ACRMI_OK;
 }

@@ -149,6 +149,10 @@ struct ManoTables {   // device pointers
   const float* jreg;         // [16][778]
   const float* weights;      // [778][16]
   const float* hands_mean;   // [45]
+  // f16 copies for ACRMI_OPT_MANO_FP16 (same layouts)
+  const unsigned short* shapedirs_h;
+  const unsigned short* posedirs_h;
+  const unsigned short* weights_h;
 };
 struct ManoArgs {
   ManoTables t[2];
@@ -160,6 +164,7 @@ struct ManoArgs {
   const float* cam; int cam_stride;
   const float* offsets; int off_div;   // offsets row = hand row / off_div
   float *verts_camed, *pj2d, *pj2d_org;
+  int lbs_f16;                         // blend-shape tables and skinning weights from their f16 copies
 };
 hipError_t launch_mano(const ManoArgs& a, hipStream_t s);
 hipError_t launch_cam_trans(const float* joints, const float* pj2d, int n, float focal, float img, float* out, hipStream_t s);

@@ -16,6 +16,10 @@ __constant__ int c_tips[2][5] = {{745, 317, 445, 556, 673}, {745, 317, 444, 556,
 
 constexpr int NV = 778, NV3 = 2334;
 
+// H16 = ACRMI_OPT_MANO_FP16 (BASELINE.json configs[4] "fp16 MANO LBS"): the blend-shape tables (shapedirs, posedirs)
+// and the skinning weights are read as f16 copies (0.73 instead of 1.46 MB of L2 traffic per side and hand), every
+// product and sum stays fp32; v_template, the joint regressor and the kinematic chain are untouched.
+template <bool H16>
 __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int side = a.side ? a.side[row] : (row & 1);
@@ -64,7 +68,8 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
   for (int i = tid; i < NV3; i += 256) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) s += T.shapedirs_t[k * NV3 + i] * sBeta[k];
+    for (int k = 0; k < 10; ++k)
+      s += (H16 ? (float)__builtin_bit_cast(_Float16, T.shapedirs_h[k * NV3 + i]) : T.shapedirs_t[k * NV3 + i]) * sBeta[k];
     sV[i] = s + T.v_template[i];
   }
   __syncthreads();
@@ -80,7 +85,8 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
   // pose blend (needs v_shaped complete for the regression above, so done after it)
   for (int i = tid; i < NV3; i += 256) {
     float s = 0.f;
-    for (int k = 0; k < 135; ++k) s += T.posedirs_t[k * NV3 + i] * sPoseMap[k];
+    for (int k = 0; k < 135; ++k)
+      s += (H16 ? (float)__builtin_bit_cast(_Float16, T.posedirs_h[k * NV3 + i]) : T.posedirs_t[k * NV3 + i]) * sPoseMap[k];
     sV[i] += s;
   }
   // kinematic chain, three levels below the root (mano/manolayer.py:187-223)
@@ -123,9 +129,10 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
 #pragma unroll
     for (int e = 0; e < 12; ++e) Tm[e] = 0.f;
     const float* wv = T.weights + v * 16;
+    const unsigned short* wh = T.weights_h + v * 16;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float w = wv[j];
+      const float w = H16 ? (float)__builtin_bit_cast(_Float16, wh[j]) : wv[j];
 #pragma unroll
       for (int e = 0; e < 12; ++e) Tm[e] += sA[j][e] * w;
     }
@@ -179,7 +186,12 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
 
 hipError_t launch_mano(const ManoArgs& a, hipStream_t s) {
   if (a.H <= 0) return hipSuccess;
-  hipLaunchKernelGGL(mano_kernel, dim3(a.H), dim3(256), 0, s, a);
+  if (a.lbs_f16) {
+    if (!a.t[0].posedirs_h || !a.t[1].posedirs_h) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mano_kernel<true>, dim3(a.H), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(mano_kernel<false>, dim3(a.H), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 

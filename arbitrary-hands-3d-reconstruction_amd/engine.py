@@ -32,6 +32,7 @@ class Engine(object):
         self.conf_thresh = 0.35
         self.center_idx = 9
         self.temporal = False
+        self.mano_fp16 = False
         self.smooth_coeff = None          # None = the library default (4.0)
         self.comm_ranks = 0
         self._mano_tables = {}
@@ -50,11 +51,12 @@ class Engine(object):
             pass
 
     # ---- setup ---------------------------------------------------------------------------------
-    def load_state_dict(self, sd, max_batch=1, keep_taps=False, precision='fp32', keep_weights=False):
+    def load_state_dict(self, sd, max_batch=1, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False):
         """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
         keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`).
         precision: 'fp32' | 'fp16' | 'bf16' (args().model_precision, acr/config.py:96; packer.lower)."""
-        self.load_program(packer.lower(sd, keep_taps=keep_taps, precision=precision, keep_weights=keep_weights), max_batch)
+        self.load_program(packer.lower(sd, keep_taps=keep_taps, precision=precision, keep_weights=keep_weights,
+                                       keep_all=keep_all), max_batch)
 
     def load_program(self, prog, max_batch=1):
         """A program lowered elsewhere (packer.lower, or another Engine's `program`): the same packed weights and op
@@ -107,6 +109,12 @@ class Engine(object):
         _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_TEMPORAL, int(bool(on))), self.ctx)
         self.temporal = bool(on)
 
+    def set_mano_fp16(self, on):
+        """ACRMI_OPT_MANO_FP16: the MANO stage reads f16 copies of its blend-shape tables and skinning weights
+        (BASELINE.json configs[4]); fp32 arithmetic."""
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_MANO_FP16, int(bool(on))), self.ctx)
+        self.mano_fp16 = bool(on)
+
     def smooth(self, slots):
         """One-Euro smoothing of slots [B,2,176] in place (acr/utils.py:1466-1527), state resident in the context."""
         if not slots.is_cuda or slots.dtype != torch.float32 or not slots.is_contiguous():
@@ -158,6 +166,7 @@ class Engine(object):
         if other.lanes:
             self.set_lanes(other.lanes)
         self.set_temporal(other.temporal, smooth_coeff=other.smooth_coeff)
+        self.set_mano_fp16(other.mano_fp16)
 
     def load_mano_side(self, name, t):
         """One side's tables (mano/manolayer.py:61-102 buffers) -> HBM, blend-shape tables transposed."""

@@ -206,10 +206,11 @@ class Blob(object):
 class Program(object):
     """Op list + buffer table under construction."""
 
-    def __init__(self, sd, dt=DT_F32, keep_weights=False):
+    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False):
         self.sd = {k: _np(v) for k, v in sd.items()}
         self.dt = dt             # storage type of the activations between layers (DT_*); head outputs stay fp32
         self.keep_weights = keep_weights
+        self.keep_all = keep_all  # no lifetime-based buffer reuse: every intermediate map survives the run (tests)
         self.blob = Blob()
         self.bufs = []           # (h, w, cs, persistent, dtype)
         self.free = {}           # (h, w, cs, dtype) -> [ids]
@@ -231,7 +232,7 @@ class Program(object):
     def release(self, *ids):
         for i in ids:
             h, w, cs, p, dt = self.bufs[i]
-            if not p:
+            if not p and not self.keep_all:
                 assert i not in self.free.setdefault((h, w, cs, dt), []), 'double release of buffer %d' % i
                 self.free[(h, w, cs, dt)].append(i)
 
@@ -437,7 +438,7 @@ def point_tower(P, side, k):
     return out
 
 
-def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False):
+def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False):
     """state dict -> dict(blob, bufs, ops, heads, op_info, taps, precision, width).  See module docstring.
     point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT; fp32 W32 only).
     keep_taps: pin the buffers of the backbone taps the golden vectors hold (stem / layer1 / stage2 / stage3 branch 0,
@@ -449,7 +450,9 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     rounding of its output; the stem conv (K = 27, reads uint8), the exits of the head towers (center, params x mix,
     prior, segm logits), attention pooling, pare bias, decode and MANO stay fp32 (the reference's .float() at
     acr/model.py:56-62).  The HRNet width (32 / 48) is read off the checkpoint.
-    keep_weights: op_info[i]['wb'] keeps the folded fp64 filters of every conv (oracle/program.py, tests only)."""
+    keep_weights: op_info[i]['wb'] keeps the folded fp64 filters of every conv (oracle/program.py, tests only).
+    keep_all: no buffer is reused, so every intermediate map can be read after a run (per-op parity tests; ~2x the
+    activation memory)."""
     sd = strip_prefix(sd)
     if check:
         check_state_dict(sd)
@@ -460,7 +463,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     c0 = width
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
-    P = Program(sd, dt, keep_weights)
+    P = Program(sd, dt, keep_weights, keep_all)
     b = 'backbone.'
     # ---- stem -----------------------------------------------------------------------------------
     w, bb = P.folded(b + 'conv1', b + 'bn1')

@@ -254,6 +254,11 @@ int acrmi_parebias(const float* pooled_dev, int C, int part0, const float* lc_w_
  * the reference's -t / temporal_optimization (acr/main.py:69-83).  The frames of a call are then ONE video stream
  * in order. */
 #define ACRMI_OPT_TEMPORAL 4
+/* ACRMI_OPT_MANO_FP16 (0/1, default 0; BASELINE.json configs[4] "fp16 MANO LBS"): the MANO stage (acrmi_mano and
+ * acrmi_forward) reads its blend-shape tables (shapedirs, posedirs) and skinning weights from f16 copies made at
+ * acrmi_load_mano - half the table traffic per hand; all products and sums stay fp32, v_template / J_regressor / the
+ * kinematic chain are untouched.  Measured deviation from the fp32 tables: see tests/test_gpu_h16.py. */
+#define ACRMI_OPT_MANO_FP16 7
 int acrmi_set_option(acrmi_ctx* ctx, int option, int value);
 /* ACRMI_OPT_CONF_THRESH (default 0.35): center score threshold, strict > (args().centermap_conf_thresh,
  * acr/result_parser.py:198-205,241).  ACRMI_OPT_SMOOTH_COEFF (default 4.0): One-Euro mincutoff of the pose filters

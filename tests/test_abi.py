@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'libacrmi.so does not export %s' % name
     assert sorted(L.EXPORTS) == declared
-    assert lib.acrmi_version() == L.VERSION == 200
+    assert lib.acrmi_version() == L.VERSION == 300
     for name in ('acrmi_allgather', 'acrmi_comm_init', 'acrmi_smooth', 'acrmi_set_option_f'):      # SURVEY.md 8b list
         assert name in declared
 
@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     L = pkg('_lib')
     assert ctypes.sizeof(L.Op) == 168 and L.Op.w_off.offset == 56 and L.Op.w_off2.offset == 136
-    assert ctypes.sizeof(L.BufferDesc) == 16 and ctypes.sizeof(L.HeadLayout) == 32
+    assert ctypes.sizeof(L.BufferDesc) == 20 and L.BufferDesc.dtype.offset == 16 and ctypes.sizeof(L.HeadLayout) == 32
+    assert (L.DT_F32, L.DT_F16, L.DT_BF16) == (0, 1, 2)
     src = open(os.path.join(ROOT, 'include', 'acrmi.h')).read()
     for name, val in (('ACRMI_SLOT', L.SLOT), ('ACRMI_SLOT_POSES', L.SLOT_POSES), ('ACRMI_SLOT_BETAS', L.SLOT_BETAS),
                       ('ACRMI_SLOT_PARAMS', L.SLOT_PARAMS), ('ACRMI_SLOT_CAM', L.SLOT_CAM)):
@@ -59,6 +60,8 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert lib.acrmi_load_weights(None, None, 0) == L.E_INVAL
     assert lib.acrmi_decode(None, 1, None, None) == L.E_INVAL
     assert lib.acrmi_conv2d(None, 1, 8, 8, 8, 0, 8, None, None, 0, None, 0, 0, None, 8, 0, 8, 3, 1, 0, 1, 0, None) == L.E_INVAL
+    assert lib.acrmi_conv2d_h16(None, 1, 8, 8, 8, 0, 8, None, None, 0, None, 0, 0, None, 8, 0, 8, 3, 1, 0, 1, 1, 0, None) == L.E_INVAL
+    assert lib.acrmi_buffer_dtype(None, 0) == -1
     assert lib.acrmi_smooth(None, None, 1, None) == L.E_INVAL
     assert lib.acrmi_set_option_f(None, L.OPT_CONF_THRESH, 0.5) == L.E_INVAL
     assert lib.acrmi_allgather(None, None, None, None, 0, None) == L.E_INVAL

@@ -61,10 +61,13 @@ def test_config_rejects_what_the_reference_rejects():
     ns = cfg.parse_args(['--configs_yml', '/nonexistent.yml'])
     assert ns.centermap_conf_thresh == 0.35 and ns.align_idx == 9 and ns.kernel_sizes == [5]
     for bad in (['--backbone', 'resnet'], ['--prior_mode', 'merge'], ['--Rot_type', 'aa'], ['--centermap_size', '32'],
-                ['--model_precision', 'fp16'], ['--attention_mode', 'none']):
+                ['--model_precision', 'int8'], ['--attention_mode', 'none']):
         with pytest.raises(ValueError):
             cfg.parse_args(['--configs_yml', '/nonexistent.yml'] + bad)
     assert cfg.parse_args(['--configs_yml', '/nonexistent.yml', '-t']).temporal_optimization is True
+    # the reference's autocast branch (acr/config.py:96, acr/model.py:33-37) and its bf16 twin are lowered as 16-bit programs
+    for prec in ('fp32', 'fp16', 'bf16'):
+        assert cfg.parse_args(['--configs_yml', '/nonexistent.yml', '--model_precision', prec]).model_precision == prec
 
 
 def test_pack_conv_layout_and_bn_folding(synth_sd):
