@@ -21,6 +21,7 @@ import time
 # must be set before the HIP runtime initialises
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -66,12 +67,15 @@ def cpu_baseline(sd, tables):
     frames = torch.from_numpy(pkg('synth').make_frames(8, seed=3))
     model, phys, logical = _cpu_model()
 
+    last = {}
+
     def run(b):
         with torch.no_grad():
             maps = acr_net.network(sd, frames[:b])
         slots = odec.decode(maps)
-        for h, name in ((0, 'left'), (1, 'right')):
-            omano.mano_forward(tables[name], name, slots['poses'][:, h], slots['betas'][:, h])
+        vj = [omano.mano_forward(tables[name], name, slots['poses'][:, h], slots['betas'][:, h])[:2]
+              for h, name in ((0, 'left'), (1, 'right'))]
+        last[b] = (slots, vj)
 
     def timed(b):
         t0 = time.perf_counter()
@@ -92,13 +96,82 @@ def cpu_baseline(sd, tables):
         res[b] = statistics.median(timed(b) for _ in range(5))
     torch.set_num_threads(prev)
     b1, b8 = 1 / res[1], 8 / res[8]
-    return {'value': round(max(b1, b8), 3), 'unit': 'frames/s', 'cores': best, 'kind': 'port',
+    slots, vj = last[8]
+    # the oracle's results on the 8 frames of the timed sample: bench.py compares the HIP path with them (`parity`)
+    oracle = {'frames': frames, 'flag': slots['flag'], 'flat_ind': slots['flat_ind'],
+              'verts': np.stack([vj[0][0], vj[1][0]], 1), 'joints': np.stack([vj[0][1], vj[1][1]], 1)}
+    return oracle, {'value': round(max(b1, b8), 3), 'unit': 'frames/s', 'cores': best, 'kind': 'port',
             'cpu_model': model, 'physical_cores': phys, 'logical_cores': logical,
             'batch1_fps': round(1 / res[1], 3), 'batch8_fps': round(8 / res[8], 3),
             'thread_probe_s_per_batch8': {str(k): round(v, 3) for k, v in probe.items()},
             'sample': 'oracle/ (torch-CPU fp32 restatement of the reference) on the same synthetic 512x512 frames; batch 1 '
                       'and batch 8, 2 warm-ups + median of 5 passes each at %d threads (best of %s); value = the better of the two '
                       '(batch %d)' % (best, sorted(probe), 1 if b1 >= b8 else 8)}
+
+
+def parity(eng, oracle):
+    """BASELINE.md 4 "parity reported alongside": the HIP path on the frames of the cpu_baseline sample against the
+    oracle's results for them - max per-vertex / per-joint L2 distance (metres) over the hands both sides detect at the
+    same center; decisions that differ are counted, not hidden."""
+    L = pkg('_lib')
+    out = eng.forward(oracle['frames'].to(eng.device))
+    torch.cuda.synchronize()
+    slots = out['slots'].cpu().numpy()
+    verts, joints = out['verts'].cpu().numpy(), out['joints'].cpu().numpy()
+    flag = slots[..., L.SLOT_FLAG] > 0.5
+    same = (flag == oracle['flag']) & (~flag | (slots[..., L.SLOT_FLATIND] == oracle['flat_ind']))
+    use = same & flag
+    dv = np.linalg.norm(verts - oracle['verts'], axis=-1)[use]
+    dj = np.linalg.norm(joints - oracle['joints'], axis=-1)[use]
+    return {'max_vertex_l2_m': float(dv.max()) if dv.size else None, 'max_joint_l2_m': float(dj.max()) if dj.size else None,
+            'frames': int(flag.shape[0]), 'hands_compared': int(use.sum()), 'decisions_differing': int((~same).sum()),
+            'against': 'oracle/ (CPU fp32 restatement pinned to the reference) on the cpu_baseline sample frames'}
+
+
+def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16', 'bf16')):
+    """Reported NEXT TO the headline, never as it: the reference's --model_precision fp16 branch (acr/model.py:33-37) and
+    its bf16 twin as 16-bit programs (packer.lower) on the same frames, same K steps, two contexts in turn like the
+    headline; `parity` = against the fp32 oracle (what 16-bit storage costs), not against a 16-bit reference (none
+    exists: autocast is CUDA-only)."""
+    res = {}
+    for prec in precisions:
+        pool = pkg('engine').EnginePool(local_rank, n=2)
+        pool.load_state_dict(sd, max_batch=B, lanes=1, precision=prec)
+        pool.load_mano(tables)
+        vsets = [pkg('parallel').alloc_result(B, pool.device)[1] for _ in range(2)]
+
+        def run(n):
+            pend = []
+            for i in range(n):
+                pend.append(pool.submit(frames, out=vsets[i % 2]))
+                while len(pend) > 1:
+                    pool.collect(pend.pop(0))
+            for t in pend:
+                pool.collect(t)
+        run(max(1, warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng = pool.engines[0]
+        prof = [p for p in eng.profile_ops(frames) if p.get('mode', 0) != pkg('_lib').MODE_POINT]
+        conv_ms = sum(p['ms'] for p in prof if p['kind'] in (pkg('_lib').OP_CONV, pkg('_lib').OP_STEM))
+        total_ms = sum(p['ms'] for p in prof)
+        flops = sum(p['flops'] for p in prof) * B
+        act_bytes = None
+        r = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+             'dtype': {'fp16': 'f16', 'bf16': 'bf16'}[prec] + ' storage, f32 accumulate (v_mfma_f32_32x32x16)',
+             'all_conv_ms_single_stream': round(conv_ms, 3), 'all_ops_ms_single_stream': round(total_ms, 3),
+             'mfma_tflops_single_stream': round(flops / (total_ms * 1e-3) / 1e12, 1), 'mfma_peak_tflops': 2500.0}
+        if oracle is not None:
+            r['parity'] = parity(eng, oracle)
+        res[prec] = r
+        pool.close()
+    res['note'] = ('16-bit programs: activations between layers f16 / bf16 NHWC, BN-folded weights rounded once, fp32 '
+                   'accumulate / bias / residual / ReLU, one rounding per layer; stem, head exits, attention pooling, '
+                   'decode, MANO fp32.  parity is against the FP32 oracle.')
+    return res
 
 
 def latency(eng, frames, views_for, batches=(1, 8), iters=20):
@@ -146,6 +219,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 / batch-8 latency measurement (profiling runs)')
     ap.add_argument('--no-point-heads', action='store_true', help='skip the separately reported point-heads variant')
+    ap.add_argument('--no-reduced-precision', action='store_true', help='skip the separately reported fp16 / bf16 programs')
     ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default, 1 per context with --pipeline >= 2)')
     ap.add_argument('--pipeline', type=int, default=2, help='contexts taking batches in turn on their own streams (engine.EnginePool): the tail of one batch overlaps the head of the next; 1 = one context')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
@@ -277,7 +351,10 @@ def main():
         # form), so frac <= 1 is the share of the fp32 MFMA peak the dominant kernel's MFMAs occupy.  The contract's
         # algorithmic figure (direct-convolution FLOPs / time) is kept next to it as algorithmic_*.
         roofline = {'bound': 'mfma', 'achieved': round(executed_tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(executed_tf / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                    'frac': round(executed_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                    'frac_definition': 'EXECUTED fp32 MFMA FLOP of the dominant kernels / launch time / peak (Winograd F(2x2,3x3) '
+                                       'executes 2.25x fewer MACs than the direct form; the algorithmic 2*MAC figure is algorithmic_frac)',
+                    'traffic': traffic, 'traffic_source': traffic_src,
                     'kernel': DOMINANT, 'launches_per_step': len(dom),
                     'algorithmic_achieved': round(achieved, 2),
                     'algorithmic_frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
@@ -324,8 +401,15 @@ def main():
                 pool = None
             eng.set_lanes(0)
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
+        oracle = None
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, tables)
+            oracle, out['cpu_baseline'] = cpu_baseline(sd, tables)
+            out['parity'] = parity(eng, oracle)
+        if world == 1 and not use_dist and not args.no_reduced_precision:
+            if pool is not None:
+                pool.close(keep_first=True)
+                pool = None
+            out['reduced_precision'] = reduced_precision(sd, tables, frames, B, args.steps, args.warmup, oracle, local_rank)
         line = json.dumps(out)
     else:
         line = None

@@ -22,10 +22,12 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--top', type=int, default=30)
     ap.add_argument('--json', default='')
+    ap.add_argument('--precision', default='fp32', help='fp32 | fp16 | bf16')
+    ap.add_argument('--width', type=int, default=32, help='HRNet width (32 | 48)')
     args = ap.parse_args()
     synth = pkg('synth')
     eng = pkg('engine').Engine(0)
-    eng.load_state_dict(synth.make_state_dict(seed=0), max_batch=args.batch)
+    eng.load_state_dict(synth.make_state_dict(seed=0, width=args.width), max_batch=args.batch, precision=args.precision)
     eng.load_mano(synth.make_mano_tables(seed=1))
     x = torch.from_numpy(synth.make_frames(args.batch, seed=0, structured=True)).cuda()
     eng.profile_ops(x)
@@ -39,8 +41,19 @@ def main():
         by[key][1] += p['ms']
     for k, (n, ms) in sorted(by.items(), key=lambda kv: -kv[1][1]):
         print('  %-34s %4d ops %8.3f ms  (%.1f us each)' % (k, n, ms, 1e3 * ms / n))
+    ops, bufs = eng.program['ops'], eng.program['bufs']
     for p in sorted(prof, key=lambda p: -p['ms'])[:args.top]:
-        print('%4d %-64s %-22s %.4f ms' % (p['idx'], p['name'], p.get('algo'), p['ms']))
+        o = ops[p['idx']]
+        shape = ''
+        if o.kind == 2:      # conv: Cin -> Cout @ output map, GFLOP/s and bytes/s of in + out + residual
+            ho, wo = bufs[o.out_buf][0], bufs[o.out_buf][1]
+            esz = lambda b: 2 if bufs[b][4] else 4
+            byt = args.batch * (bufs[o.in_buf][0] * bufs[o.in_buf][1] * o.cin * o.groups * esz(o.in_buf) +
+                                ho * wo * o.cout * o.groups * esz(o.out_buf) * (2 if o.res_buf >= 0 else 1))
+            shape = '%dx%d->%d@%dx%d g%d  %6.1f TF  %5.2f TB/s' % (o.groups, o.cin, o.cout, ho, wo, o.groups,
+                                                                     p['flops'] * args.batch / p['ms'] / 1e9,
+                                                                     byt / p['ms'] / 1e9)
+        print('%4d %-48s %-22s %.4f ms  %s' % (p['idx'], p['name'][-48:], p.get('algo'), p['ms'], shape))
     if args.json:
         with open(args.json, 'w') as f:
             json.dump(prof, f)
