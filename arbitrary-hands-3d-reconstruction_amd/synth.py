@@ -168,6 +168,61 @@ def make_hostile_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefi
     return _as_torch(out) if as_torch else out
 
 
+def plant_center_peaks(sd, left=None, right=None, radius_px=6.0, amplitude=3.0, width=32):
+    """Edits a checkpoint (dict of numpy float32 arrays, bare keys) IN PLACE so that the center map of a side peaks at a
+    chosen INTERIOR pixel (y, x) of the 64x64 map, whatever the frame shows - a position-dependent center bias built from
+    the two coordinate channels the head towers see (acr/model.py:52,340-369), through the tower's own layers:
+      entry conv (3x3 s2), channels 60-63:  a_x = relu((X - X0)/r), b_x = relu((X0 - X)/r), a_y, b_y   (channel 59: 0)
+      block 0 conv1, channels 60 / 61:      tent_x = relu(1 - a_x - b_x), tent_y = relu(1 - a_y - b_y)
+      block 0 conv2 + residual, channel 59: bump = relu(tent_x + tent_y)            (2 at the peak, 1 on its two ridges)
+      block 1: channel 59 passes through;   exit conv: center += amplitude * bump.
+    The synthetic network's own center maps are bias-dominated and peak on the map border (zero padding); with this
+    the reference, the oracle and the kernels are exercised on centers whose 5x5 NMS window, 3x3 taps and 9x9 point-heads
+    window lie fully inside the map.  None leaves a side untouched."""
+    c0 = width
+    for side, peak in (('l', left), ('r', right)):
+        if peak is None:
+            continue
+        y0, x0 = peak
+        pre = '%s_final_layers.2' % side
+        sp = slice(59, 64)
+        r = radius_px * 4.0 / 127.0                       # coordinate units per output pixel: 2 * 2 / 127
+
+        def ident_bn(name, ch, beta):
+            sd[name + '.weight'][ch] = 1.0
+            sd[name + '.bias'][ch] = beta
+            sd[name + '.running_mean'][ch] = 0.0
+            sd[name + '.running_var'][ch] = 1.0
+        # entry conv: coordinates at the centre tap (input pixel 2*o of the 128-map)
+        X0 = np.float32(np.float32(2 * x0) / np.float32(127) * 2 - 1)
+        Y0 = np.float32(np.float32(2 * y0) / np.float32(127) * 2 - 1)
+        w, b = sd[pre + '.0.0.weight'], sd[pre + '.0.0.bias']
+        w[sp] = 0.0
+        b[sp] = 0.0
+        for ch, (cin, sign, ref) in zip((60, 61, 62, 63), ((c0, 1, X0), (c0, -1, X0), (c0 + 1, 1, Y0), (c0 + 1, -1, Y0))):
+            w[ch, cin, 1, 1] = sign / r
+            ident_bn(pre + '.0.1', ch, -sign * ref / r)
+        ident_bn(pre + '.0.1', 59, 0.0)
+        for blk in (0, 1):
+            for conv, bn in (('conv1', 'bn1'), ('conv2', 'bn2')):
+                wk = sd['%s.1.%d.0.%s.weight' % (pre, blk, conv)]
+                wk[sp] = 0.0                                # special output channels: built below
+                wk[:, sp] = 0.0                             # ... and invisible to the ordinary channels
+                for ch in range(59, 64):
+                    ident_bn('%s.1.%d.0.%s' % (pre, blk, bn), ch, 0.0)
+        w1 = sd[pre + '.1.0.0.conv1.weight']
+        w1[60, 60, 1, 1] = w1[60, 61, 1, 1] = -1.0
+        w1[61, 62, 1, 1] = w1[61, 63, 1, 1] = -1.0
+        sd[pre + '.1.0.0.bn1.bias'][60] = 1.0
+        sd[pre + '.1.0.0.bn1.bias'][61] = 1.0
+        w2 = sd[pre + '.1.0.0.conv2.weight']
+        w2[59, 60, 1, 1] = w2[59, 61, 1, 1] = 1.0
+        we = sd[pre + '.2.weight']
+        we[0, sp] = 0.0
+        we[0, 59] = amplitude
+    return sd
+
+
 def _is_bn(key, sch):
     """True for BatchNorm weight/bias tensors (their module also owns a running_mean)."""
     base = key.rsplit('.', 1)[0]

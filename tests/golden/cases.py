@@ -114,3 +114,19 @@ def smooth_inputs(n_frames=14, seed=41):
 # (found by scanning seeds with the pinned oracle; seed 0 = both hands, centres 63 px apart, is e2e_batch1.npz)
 STATE_CHECKPOINTS = {'both_near': 10, 'left_only': 3, 'right_only': 11, 'none': 7}
 STATE_FRAME_SEED = 5
+
+
+# ---- interior centers through the real reference (G12): planted center peaks (synth.plant_center_peaks) ----------------
+# name -> (checkpoint seed, left (y, x), right (y, x)); every peak >= 9 px from every border of the 64x64 map
+INTERIOR_CASES = {
+    'near': (0, (20, 30), (40, 12)),        # 26.9 px apart: the cross-hand prior is applied
+    'far': (10, (12, 10), (50, 52)),        # 56.6 px apart: priors zeroed (acr/result_parser.py:42-47)
+    'mid': (3, (32, 33), (33, 20)),
+}
+
+
+def interior_state_dict(synth, name, as_torch=True):
+    seed, lp, rp = INTERIOR_CASES[name]
+    sd = synth.make_state_dict(seed=seed, as_torch=False)
+    synth.plant_center_peaks(sd, left=lp, right=rp)
+    return synth._as_torch(sd) if as_torch else sd

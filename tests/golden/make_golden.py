@@ -173,6 +173,27 @@ def main():
         print('state', name, 'seed', seed, 'flags', st[name + '_f0_detection_flag'], st[name + '_f1_detection_flag'],
               'centers', st[name + '_f0_l_centers_pred'].tolist(), st[name + '_f0_r_centers_pred'].tolist())
     np.savez_compressed(os.path.join(HERE, 'e2e_states.npz'), **st)
+
+    # ---- G12: INTERIOR centers through the whole network: the synthetic network's own center maps
+    # peak on the map border, so a position-dependent center bias is planted into the checkpoint's center towers
+    # (synth.plant_center_peaks: plain weights, the reference runs them as it runs any checkpoint) ------------------
+    it = {}
+    for name in cases.INTERIOR_CASES:
+        model.load_state_dict(cases.interior_state_dict(synth, name), strict=True)
+        for b in range(2):
+            meta = {'image': sframes[b:b + 1], 'offsets': torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]),
+                    'batch_ids': torch.arange(1), 'imgpath': ['i%d' % b]}
+            with torch.no_grad():
+                o = model(meta, mode='parsing', calc_loss=False)
+                o = wrapper(o, o['meta_data'])
+            for k in ('params_pred', 'detection_flag', 'l_centers_pred', 'r_centers_pred', 'l_centers_conf',
+                      'r_centers_conf', 'output_hand_type', 'verts', 'j3d', 'pj2d', 'cam_trans'):
+                it['%s_f%d_%s' % (name, b, k)] = o[k].numpy()
+            for k in ('cam', 'poses', 'betas'):
+                it['%s_f%d_%s' % (name, b, k)] = o['params_dict'][k].numpy()
+        print('interior', name, 'flags', it[name + '_f0_detection_flag'], 'centers (x, y)',
+              it[name + '_f0_l_centers_pred'].tolist(), it[name + '_f0_r_centers_pred'].tolist())
+    np.savez_compressed(os.path.join(HERE, 'e2e_interior.npz'), **it)
     model.load_state_dict(sd, strict=True)
 
     # ---- G11: BASELINE configs[0] - demo/magic.jpg through the reference's img_preprocess + model + MANO --

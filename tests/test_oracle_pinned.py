@@ -165,6 +165,53 @@ def test_network_states_match_reference(name, mano_tables):
         assert np.hypot(*(lc - rc).astype(float)) <= 32
 
 
+@pytest.mark.parametrize('name', list(cases.INTERIOR_CASES))
+def test_interior_centers_match_reference(name, mano_tables):
+    """centers >= 9 px from every border of the map (planted with synth.plant_center_peaks; every other
+    whole-network fixture peaks on the border) through the WHOLE network == the real reference (e2e_interior.npz)."""
+    g = golden('e2e_interior.npz')
+    torch.set_num_threads(8)
+    seed, lp, rp = cases.INTERIOR_CASES[name]
+    sd = cases.interior_state_dict(pkg('synth'), name)
+    frames = torch.from_numpy(pkg('synth').make_frames(2, seed=cases.STATE_FRAME_SEED))
+    with torch.no_grad():
+        heads = acr_net.network(sd, frames)
+    slots = odec.decode(heads)
+    for b in range(2):
+        rows = odec.slots_to_rows({k: v[b:b + 1] for k, v in slots.items()})
+        key = '%s_f%d_' % (name, b)
+        assert g[key + 'detection_flag'].tolist() == [1.0, 1.0] and rows['detection_flag'].tolist() == [True, True]
+        lc, rc = g[key + 'l_centers_pred'][0], g[key + 'r_centers_pred'][0]          # (x, y)
+        assert (lc[1], lc[0]) == lp and (rc[1], rc[0]) == rp                          # the reference found the planted pixels
+        assert all(5 <= v <= 58 for v in (*lp, *rp))
+        assert rows['flat_ind'][0] == lp[0] * 64 + lp[1] and rows['flat_ind'][1] == rp[0] * 64 + rp[1]
+        _close(rows['params_pred'], g[key + 'params_pred'], 2e-4, 2e-4)
+        vl, jl, _ = omano.mano_forward(_tables(mano_tables, 'l'), 'left', rows['poses'][:1], rows['betas'][:1])
+        vr, jr, _ = omano.mano_forward(_tables(mano_tables, 'r'), 'right', rows['poses'][1:], rows['betas'][1:])
+        assert np.abs(np.concatenate([vl, vr]) - g[key + 'verts']).max() < 2e-5
+        assert np.abs(np.concatenate([jl, jr]) - g[key + 'j3d']).max() < 2e-5
+
+
+def test_hostile_checkpoint_is_the_same_function():
+    """synth.make_state_dict(law='hostile') re-parametrises the benign checkpoint (raw conv rows over 2.5 decades with
+    running_var over 1e-3..1e2, block-internal channel scales over two decades, backbone stream x50) without changing
+    the function: the oracle gives the benign maps to fp32 round-off while the stream runs at ~50x the magnitude."""
+    synth = pkg('synth')
+    torch.set_num_threads(8)
+    sd, hs = synth.make_state_dict(seed=0), synth.make_state_dict(seed=0, law='hostile')
+    rv = torch.cat([v.flatten() for k, v in hs.items() if k.endswith('running_var')])
+    assert float(rv.min()) < 2e-3 and float(rv.max()) > 50 and float(rv.min()) > 0
+    frame = torch.from_numpy(synth.make_frames(1, seed=0))
+    ta, tb = {}, {}
+    with torch.no_grad():
+        a, b = acr_net.network(sd, frame, ta), acr_net.network(hs, frame, tb)
+    for k in a:
+        assert float((a[k] - b[k]).abs().max()) < 5e-5 * max(1.0, float(a[k].abs().max())), k
+    for k in ('stem', 'layer1', 'stage2', 'stage3'):
+        assert float((ta[k] * 50 - tb[k]).abs().max()) < 1e-4 * float(tb[k].abs().max()), k
+    assert float(tb['stage3'].abs().max()) > 50
+
+
 def test_smoothing_oracle_matches_reference_sequence():
     """oracle.smooth (numpy f32) == the reference's smooth_results / OneEuroFilter over a 14-frame two-hand sequence
     with a late-appearing hand, a two-frame drop-out and a near-pi global orientation (smooth_seq.npz)."""
