@@ -32,7 +32,7 @@ GFLOP_PER_FRAME = 102.1          # BASELINE.md §3 / SURVEY.md §8d (2*MAC, dire
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
 DOMINANT = 'conv_wino2_kernel + conv_wino3_kernel (3x3 stride-1 convolutions, Winograd F(2x2,3x3) on fp32 MFMA)'
 MFMA_REDUCTION = {'winograd_f2x2_3x3': 2.25, 'winograd_f2x2_3x3_lds': 2.25, 'winograd_f23x': 1.5}   # algorithmic MACs per executed MFMA MAC
-PROFILE_TAGS = ('r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
+PROFILE_TAGS = ('r03', 'r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
 
 
 def pkg(sub):
@@ -174,6 +174,92 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
     return res
 
 
+def live_pmc(batch, timeout_s=300):
+    """the PMC figures of the bench line measured in THIS run instead of read from profiles/ - bench.py
+    re-executes itself (one warm-up + one step, one context, one stream) under `rocprofv3 --kernel-trace --pmc ...`, in
+    two passes because FETCH_SIZE and WRITE_SIZE do not fit the TCC's counter slots together (MI355X_MICROARCH.md); no
+    other trace domain is enabled.  gfx950 correction: FETCH_SIZE x 2 (wide coalesced reads are reported at half),
+    WRITE_SIZE as is, both in KiB.  Returns None when rocprofv3 is absent or a pass fails (the caller falls back to the
+    committed profiles/ files and says so)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which('rocprofv3')
+    if not exe:
+        return None
+    passes = [('fetch', ['FETCH_SIZE', 'SQ_BUSY_CU_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES']), ('write', ['WRITE_SIZE'])]
+    tot = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(set))
+    tmp = tempfile.mkdtemp(prefix='acrmi_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for tag, counters in passes:
+            out = os.path.join(tmp, tag)
+            cmd = [exe, '--output-format', 'csv', '--kernel-trace', '--pmc'] + counters + ['-d', out, '-o', 'p', '--', sys.executable,
+                   os.path.join(ROOT, 'bench.py'), '--pmc-child', '--batch', str(batch)]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+            if not files:
+                return None
+            for path in files:
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        name = re.sub(r'\(.*$', '', re.sub(r'^void ', '', row['Kernel_Name'])).replace('acrmi::', '')
+                        tot[name][row['Counter_Name']] += float(row['Counter_Value'])
+                        cnt[name][row['Counter_Name']].add(row['Dispatch_Id'])
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fam = defaultdict(lambda: {'fetch': 0.0, 'write': 0.0, 'launches': 0})
+    variants, wsum = {}, defaultdict(lambda: [0.0, 0.0])
+    for name, c in tot.items():
+        if 'conv_' not in name:
+            continue
+        base = re.sub(r'<.*', '', name)
+        n = len(cnt[name].get('FETCH_SIZE', ())) or len(cnt[name].get('WRITE_SIZE', ()))
+        fam[base]['fetch'] += 2.0 * 1024.0 * c.get('FETCH_SIZE', 0.0)
+        fam[base]['write'] += 1024.0 * c.get('WRITE_SIZE', 0.0)
+        fam[base]['launches'] += n
+        busy, mfma = c.get('SQ_BUSY_CU_CYCLES', 0.0), c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+        if busy >= 1e8:
+            variants[name] = {'launches': n, 'mfma_busy_frac': round(mfma / (4 * busy), 4)}
+            for k in ('conv_wino' if 'wino' in name else 'conv_direct', 'all_convs'):
+                wsum[k][0] += mfma
+                wsum[k][1] += 4 * busy
+    traffic = {k: {'launches_profiled': v['launches'], 'hbm_bytes_per_launch': round((v['fetch'] + v['write']) / max(1, v['launches'])),
+                   'fetch_bytes_per_launch': round(v['fetch'] / max(1, v['launches'])),
+                   'write_bytes_per_launch': round(v['write'] / max(1, v['launches']))} for k, v in fam.items()}
+    return {'traffic': traffic,
+            'mfma_busy': {'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), summed over launches',
+                          'cycle_weighted': {k: round(v[0] / v[1], 4) for k, v in wsum.items() if v[1]}, 'variants': variants},
+            'source': 'measured in this run: rocprofv3 --kernel-trace --pmc (2 passes) on `bench.py --pmc-child` (1 warm-up + 1 '
+                      'step, batch %d, one context, one stream); FETCH_SIZE x 2 (gfx950), WRITE_SIZE exact' % batch}
+
+
+def pmc_child(batch):
+    """The workload live_pmc() profiles: the fp32 headline program, one warm-up + one step on one stream."""
+    synth = pkg('synth')
+    tables = synth.make_mano_tables(seed=1)
+    tables['left']['shapedirs'] = tables['left']['shapedirs'].copy()
+    tables['left']['shapedirs'][:, 0, :] *= -1
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth.make_state_dict(seed=0), max_batch=batch)
+    eng.load_mano(tables)
+    eng.set_lanes(1)
+    frames = torch.from_numpy(synth.make_frames(batch, seed=0, structured=False)).cuda()
+    views = pkg('parallel').alloc_result(batch, eng.device)[1]
+    for _ in range(2):
+        eng.forward(frames, out=views)
+    torch.cuda.synchronize()
+
+
 def latency(eng, frames, views_for, batches=(1, 8), iters=20):
     """Per-call latency at the batch sizes the reference is actually called with (acr/main.py:126-141 runs batch 1)."""
     out = {}
@@ -210,6 +296,35 @@ def point_heads_rate(set_point_heads, run_steps, B, steps, warmup):
                     'dense params/prior maps not produced'}
 
 
+def run_pipelined(n, frames, eng=None, pool=None, runner=None, vsets=None):
+    """n steps of the bench's step loop; returns what the last step produced.
+      * one context, no pool: eng.forward back to back on the current stream;
+      * a pool of contexts (engine.EnginePool): batches submitted in turn, len(pool) - 1 tickets left outstanding behind a
+        submit - batch k's tail overlaps batch k+1's head;
+      * a ShardedRunner (N > 1): submit queues forward + all-gather of this rank's shard, ONE ticket stays outstanding so
+        that batch k's gather overlaps batch k+1's backbone (the runner double-buffers its results: a third outstanding
+        ticket would overwrite batch k).
+    Module level so that tests/test_parallel_gloo.py can drive the N > 1 loop over gloo with CPU stand-ins."""
+    last = None
+    if runner is None and pool is None:
+        for _ in range(n):
+            last = eng.forward(frames, out=vsets[0])
+        return last
+    pending = []
+    depth = 1 if runner is not None else len(pool) - 1     # tickets left outstanding behind a submit
+    for i in range(n):
+        if runner is not None:
+            pending.append((runner, runner.submit(frames)))
+        else:
+            pending.append((pool, pool.submit(frames, out=vsets[i % len(vsets)])))
+        while len(pending) > depth:
+            who, t = pending.pop(0)
+            last = who.collect(t)
+    for who, t in pending:
+        last = who.collect(t)
+    return last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -220,11 +335,16 @@ def main():
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 / batch-8 latency measurement (profiling runs)')
     ap.add_argument('--no-point-heads', action='store_true', help='skip the separately reported point-heads variant')
     ap.add_argument('--no-reduced-precision', action='store_true', help='skip the separately reported fp16 / bf16 programs')
+    ap.add_argument('--no-pmc', action='store_true', help='do not re-run one step under rocprofv3 --pmc; roofline.traffic / mfma_busy_pmc then come from profiles/')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default, 1 per context with --pipeline >= 2)')
     ap.add_argument('--pipeline', type=int, default=2, help='contexts taking batches in turn on their own streams (engine.EnginePool): the tail of one batch overlaps the head of the next; 1 = one context')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
     args = ap.parse_args()
 
+    if args.pmc_child:
+        pmc_child(args.batch)
+        return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -280,22 +400,7 @@ def main():
         runner = parallel.ShardedRunner(local, eng.device, engine=eng)
 
     def run_steps(n):
-        if runner is None and pool is None:
-            for _ in range(n):
-                eng.forward(frames, out=views)
-            return
-        pending = []
-        depth = 1 if runner is not None else len(pool) - 1     # tickets left outstanding behind a submit
-        for i in range(n):
-            if runner is not None:
-                pending.append((runner, runner.submit(frames)))
-            else:
-                pending.append((pool, pool.submit(frames, out=vsets[i % npipe])))
-            while len(pending) > depth:
-                who, t = pending.pop(0)
-                who.collect(t)
-        for who, t in pending:
-            who.collect(t)
+        return run_pipelined(n, frames, eng=eng, pool=pool, runner=runner, vsets=vsets)
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
@@ -401,6 +506,17 @@ def main():
                 pool = None
             eng.set_lanes(0)
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
+        if world == 1 and not use_dist and not args.no_pmc:
+            # counters of THIS box, THIS run (the committed profiles/ figures stay as the fallback, labelled as such)
+            live = live_pmc(B)
+            if live is not None:
+                t2 = live['traffic'].get('conv_wino2_kernel', {}).get('hbm_bytes_per_launch')
+                out['roofline']['traffic'] = t2 or out['roofline']['traffic']
+                out['roofline']['traffic_source'] = live['source'] if t2 else out['roofline']['traffic_source']
+                out['roofline']['traffic_per_kernel'] = live['traffic']
+                out['roofline']['mfma_busy_pmc'] = dict(live['mfma_busy'], source=live['source'])
+            else:
+                out['roofline']['traffic_source'] = 'committed: ' + str(out['roofline']['traffic_source'])
         oracle = None
         if world == 1 and not args.no_cpu_baseline:
             oracle, out['cpu_baseline'] = cpu_baseline(sd, tables)

@@ -114,6 +114,97 @@ def test_sharded_forward_equals_single_process(mano_tables):
             np.testing.assert_array_equal(got[k], want[k])     # every rank holds the full, ordered result
 
 
+class _CpuPool(object):
+    """engine.EnginePool's surface (submit / release / collect / len) over the CPU stand-in forward: what bench.py's
+    N > 1 step loop drives through parallel.ShardedRunner."""
+
+    def __init__(self, fwd, n=2):
+        self.fwd, self.n, self.busy, self.turn, self.submits = fwd, n, [None] * n, 0, 0
+
+    def __len__(self):
+        return self.n
+
+    def submit(self, frames, out=None):
+        i = self.turn
+        assert self.busy[i] is None, 'ticket of %d submits ago not collected / released' % self.n
+        self.turn = (i + 1) % self.n
+        self.fwd(frames, out)
+        self.submits += 1
+        t = {'slot': i, 'out': out}
+        self.busy[i] = t
+        return t
+
+    def release(self, t):
+        self.busy[t['slot']] = None
+        return None            # (a GPU pool returns the batch's event)
+
+    def collect(self, t):
+        self.release(t)
+        return t['out']
+
+
+def _bench_worker(rank, world, port, q):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'tests', 'golden'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import importlib
+        bench = importlib.import_module('bench')
+        parallel = importlib.import_module(PKG + '.parallel')
+        synth = importlib.import_module(PKG + '.synth')
+        tables = synth.make_mano_tables(seed=1)
+        pool = _CpuPool(_oracle_forward(tables), n=2)
+        # exactly bench.py's wiring for N > 1 with a pool (bench.py main(): `local`, `runner`, npipe = min(npipe, 2))
+        local = lambda f, v: pool.release(pool.submit(f, out=v))
+        runner = parallel.ShardedRunner(local, torch.device('cpu'))
+        lo, hi = parallel.shard_range(len(NAMES), rank, world)
+        frames = _frames(len(NAMES))[lo:hi]
+        last = bench.run_pipelined(5, frames, pool=pool, runner=runner)
+        ok = pool.submits == 5 and not runner._pending and all(b is None for b in pool.busy)
+        # the single-context loop and the pool loop of the same function (N = 1 forms), on this rank's shard
+        flat, views = parallel.alloc_result(hi - lo, torch.device('cpu'))
+
+        class _Eng(object):
+            def forward(self, f, out=None):
+                _oracle_forward(tables)(f, out)
+                return out
+        one = bench.run_pipelined(2, frames, eng=_Eng(), vsets=[views])
+        vs = [parallel.alloc_result(hi - lo, torch.device('cpu'))[1] for _ in range(2)]
+        two = bench.run_pipelined(3, frames, pool=_CpuPool(_oracle_forward(tables), n=2), vsets=vs)
+        ok = ok and all(torch.equal(one[k], two[k]) for k in ('slots', 'verts', 'joints'))
+        q.put((rank, {k: v.numpy() for k, v in last.items()}, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_loop_over_gloo(mano_tables):
+    """the N > 1 code path of bench.py itself - run_pipelined with a ShardedRunner over a pool, one
+    ticket left outstanding, results double-buffered - executed at world size 2 (gloo, CPU stand-ins) before hardware
+    sees it: it terminates, every ticket is collected, and every rank ends with the full ordered result."""
+    parallel = pkg('parallel')
+    flat, views = parallel.alloc_result(len(NAMES), torch.device('cpu'))
+    _oracle_forward(mano_tables)(_frames(len(NAMES)), views)
+    want = {k: v.numpy().copy() for k, v in views.items()}
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, ok in res:
+        assert ok
+        for k in ('slots', 'verts', 'joints'):
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-6)
+
+
 def test_shard_range_and_buffer_layout():
     parallel = pkg('parallel')
     assert parallel.shard_range(512, 3, 8) == (192, 256)
