@@ -217,7 +217,7 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       a.cin8 = (op.cin + 7) / 8;
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
-      a.algo = op.flags & 3;
+      a.algo = op.flags & 7;
       a.dtype = di.dtype;                                    // 16-bit input: conv_h16.hip
       a.out_f32 = di.dtype != ACRMI_DT_F32 && dout.dtype == ACRMI_DT_F32;
       HIPCHK(c, launch_conv(a, s));
@@ -446,7 +446,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       if (op.in_coff % (idt ? 8 : 4) || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2 || op.cin <= 0 || op.cout <= 0 ||
           op.groups <= 0 || (op.ksize == 1 && op.stride != 1))
         return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
-      const int algo = op.flags & 3;
+      const int algo = op.flags & 7;
+      if (algo > 4) return fail(c, ACRMI_EINVAL, "op %d: unknown conv algo %d", i, algo);
       // 16-bit input: direct kernel only; the output is 16-bit too or fp32 (a head exit; 1x1 and 3x3 stride 1), a residual
       // has the type of the output.  fp32 input: everything fp32.
       if (idt ? (algo != 0 || (odt != idt && odt != ACRMI_DT_F32) || (odt == ACRMI_DT_F32 && op.stride != 1) ||
@@ -471,7 +472,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
           (op.res_buf >= 0 && (bufs[op.res_buf].h != ho || bufs[op.res_buf].w != wo)))
         return fail(c, ACRMI_EINVAL, "op %d: output/residual buffer geometry does not match the convolution", i);
       const long long n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
-      const long long taps = algo >= 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize);
+      if (algo == 4 && op.cin <= 16) return fail(c, ACRMI_EINVAL, "op %d: algo 4 needs Cin > 16 (two 16-channel chunks per item)", i);
+      const long long taps = algo == 4 ? 24 : (algo >= 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize));
       const long long ksteps = idt ? (op.cin + 15) / 16 : (op.cin + 7) / 8;      // 1 KiB weight fragments per tap and n-tile
       const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ksteps * n_tiles * 256;
       if (!w_ok(op.w_off, wn)) return fail(c, ACRMI_EINVAL, "op %d: packed weights outside the blob", i);
@@ -911,11 +913,12 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  void* stream) {
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0)
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
-  if (algo != 0 && !((algo >= 1 && algo <= 3) && ksize == 3 && stride == 1))
+  if (algo != 0 && !((algo >= 1 && algo <= 4) && ksize == 3 && stride == 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-1 convolution", algo);
   if (algo == 3 && (groups != 1 || cin > 32 || cout != 32 || bias_frame_stride != 0 || H % 8 || W % 16 || out_cs % 4 ||
                     out_coff % 4 || (res && (res_cs % 4 || res_coff % 4))))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 3 needs groups 1, Cin <= 32, Cout = 32, H %% 8 == 0, W %% 16 == 0");
+  if (algo == 4 && cin <= 16) return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 4 needs Cin > 16");
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))

@@ -527,6 +527,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 #include "conv_wino2.inc"
 #include "conv_ws2.inc"
 #include "conv_wino3.inc"
+#include "conv_wino24.inc"
 
 // Tile selection.  N32: one 32-cout tile per wave (Cout <= 32); N64: two.
 // Small frames (<=16x16 outputs) take the 8x16 pixel tile so a batch still fills 256 CUs.
@@ -561,6 +562,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   if (a.dtype != ACRMI_DT_F32) return launch_conv_h16(a, s);   // f16 / bf16 storage: conv_h16.hip
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
+  if (a.algo == 4) return launch_wino24(a, s);  // F(2x4,3x3): weights packed with 4x6 taps
   if (a.algo == 3) return launch_wino3(a, s);   // F(2x2,3x3), Cin <= 32, Cout = 32: weights packed for LDS residency
   if (a.algo == 2) {   // Winograd F(2x2,3x3): 3x3 stride 1 only, weights packed with 16 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;
@@ -614,6 +616,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
 
 const char* conv_kernel_name(const ConvArgs& a) {
   if (a.dtype != ACRMI_DT_F32) return a.dtype == ACRMI_DT_BF16 ? "conv_direct_mfma_bf16" : "conv_direct_mfma_f16";
+  if (a.algo == 4) return "conv3x3s1_wino2x4_mfma_f32";
   if (a.algo == 3) return "conv3x3s1_wino2d_lds_mfma_f32";
   if (a.algo == 2) return "conv3x3s1_wino2d_mfma_f32";
   if (a.algo == 1) return "conv3x3s1_wino_mfma_f32";

@@ -159,6 +159,17 @@ def winograd2d_weights(w):
     return np.einsum('uy,vx,oiyx->oiuv', WINO_G, WINO_G, np.asarray(w, np.float64))
 
 
+WINO_G4 = np.array([[1 / 4.0, 0.0, 0.0], [-1 / 6.0, -1 / 6.0, -1 / 6.0], [-1 / 6.0, 1 / 6.0, -1 / 6.0],
+                    [1 / 24.0, 1 / 12.0, 1 / 6.0], [1 / 24.0, -1 / 12.0, 1 / 6.0], [0.0, 0.0, 1.0]])
+
+
+def winograd24_weights(w):
+    """[Cout,Cin,3,3] -> [Cout,Cin,4,6]: Winograd F(2x4,3x3) weight transform U = G2 g G4^T - F(2,3) along y, F(4,3) along
+    x (fp64 in, rounded once by pack_conv).  conv_wino24_kernel consumes them as 4x6 'taps' (py, px)."""
+    assert w.shape[2:] == (3, 3)
+    return np.einsum('uy,vx,oiyx->oiuv', WINO_G, WINO_G4, np.asarray(w, np.float64))
+
+
 def use_winograd(k, stride):
     return k == 3 and stride == 1
 
@@ -168,13 +179,23 @@ def use_winograd(k, stride):
 WINOGRAD_LDS = True
 
 
+# F(2x4,3x3) (algo 4, conv_wino24.inc: F(4,3) along x, 1.33x fewer MFMAs than F(2x2,3x3), ~10x its round-off) for the
+# layers with Cin >= 32 on maps at least one 32-pixel tile wide.  OFF: built, parity-green (19 kernel cases) and measured
+# in round 3 - with the 16-channel chunks its LDS budget forces (two 10x34 patches + 16 parked tiles) an item spends 44 %
+# of its cycles in MFMAs against conv_wino2_kernel's 64 %, which eats the 1.33x: 0.112 vs 0.108 ms (64->64 @64x64), 0.105
+# vs 0.099 ms (128->128 @32x32) at batch 64 (tools/conv_bench.py --wino24).
+WINOGRAD_24 = False
+
+
 def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False):
-    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps."""
+    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3)."""
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
     if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
             and not per_frame_bias):
         return 3
+    if WINOGRAD_2D and WINOGRAD_24 and cin >= 32 and cout != 33 and wo % 32 == 0 and ho % 8 == 0:
+        return 4
     return 2 if WINOGRAD_2D else 1
 
 
@@ -321,7 +342,7 @@ class Program(object):
             if algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:
-                tr = (lambda t: t, winograd_weights, winograd2d_weights)[algo]
+                tr = (lambda t: t, winograd_weights, winograd2d_weights, None, winograd24_weights)[algo]
                 packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
             w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
@@ -330,7 +351,8 @@ class Program(object):
                  in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
                  relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=algo,
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
-        self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds')[algo]
+        self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
+                                    'winograd_f2x4_3x3')[algo]
         if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
             self.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for (w, b) in wb_list]
         return out

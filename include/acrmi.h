@@ -91,7 +91,7 @@ typedef struct {
   int32_t nterms;                         /* FUSESUM */
   int32_t term_buf[4], term_coff[4], term_shift[4];
   int64_t w_off2, b_off2, w_off3;         /* PAREBIAS: linear weights/bias, mix-conv pare columns */
-  int32_t flags;                          /* CONV: algo (bits 0-1); PAREBIAS: part slice start (0 right /
+  int32_t flags;                          /* CONV: algo (bits 0-2); PAREBIAS: part slice start (0 right /
                                              16 left); POINTHEADS: side (0 left / 1 right)   */
   int32_t mode;                           /* ACRMI_MODE_*                                    */
 } acrmi_op;
@@ -192,7 +192,9 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
  * 1 = Winograd F(2,3) along x (3x3 stride 1 only; w_packed = pack_conv(winograd_weights(w)));
  * 2 = Winograd F(2x2,3x3) (3x3 stride 1 only; w_packed = pack_conv(winograd2d_weights(w)));
  * 3 = Winograd F(2x2,3x3) with the layer's taps resident in LDS (groups 1, Cin <= 32, Cout = 32, H % 8 == 0,
- *     W % 16 == 0; w_packed = pack_wino3(w), 64 KiB). */
+ *     W % 16 == 0; w_packed = pack_wino3(w), 64 KiB);
+ * 4 = Winograd F(2x4,3x3): F(2,3) along y, F(4,3) along x (3x3 stride 1, Cin > 16; w_packed =
+ *     pack_conv(winograd24_weights(w)), 4x6 taps). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,

@@ -136,6 +136,41 @@ def test_conv2d_winograd2d_matches_torch(ops, case):
         assert out[..., cout:].abs().max().item() == 0.0
 
 
+WINO24_CASES = [c for c in WINO2D_CASES if c[1] // c[7] > 16 and c[2] != 33] + [
+    (2, 64, 64, 64, 64, 3, 1, 1, True, True),        # branch 1: 4 chunks of 16 channels, 2 n-tiles
+    (2, 128, 128, 32, 32, 3, 1, 1, True, False),     # branch 2: one 32-pixel tile column, 8 chunks
+    (1, 32, 64, 8, 32, 3, 1, 1, False, False),       # exactly two chunks, one tile
+    (1, 40, 64, 16, 64, 3, 1, 1, True, True),        # 2.5 chunks: the last chunk is a single (tail) step
+    (1, 24, 16, 11, 45, 3, 1, 1, True, True),        # 1.5 chunks, ragged tile, Cout < 32
+    (2, 128, 128, 32, 32, 3, 1, 2, True, True),      # groups
+]
+
+
+@pytest.mark.parametrize('case', WINO24_CASES, ids=lambda c: 'wino24_B%d_%dto%d_%dx%d_g%d' % (c[0], c[1], c[2], c[3], c[4], c[7]))
+def test_conv2d_winograd24_matches_torch(ops, case):
+    """3x3 stride-1 convolutions through the Winograd F(2x4,3x3) kernel (F(2,3) along y, F(4,3) along x) vs an fp64
+    direct convolution.  F(4,3) carries ~10x the round-off of F(2,3) in fp32."""
+    B, cin, cout, H, W, k, stride, groups, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 24)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, k, k, generator=g) / np.sqrt(cin // groups * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1, 1, groups)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv2d(ops.to_nhwc(x), w, b, relu=relu, groups=groups, cin=cin // groups, algo='winograd24',
+                     residual=None if res is None else ops.to_nhwc(res))
+    torch.cuda.synchronize()
+    err = (_nchw(out, cout).double() - ref).abs().max().item()
+    assert err < 2e-4, err
+    if out.shape[-1] > cout:
+        assert out[..., cout:].abs().max().item() == 0.0
+
+
 WINO3_CASES = [
     # B, Cin, H, W, relu, residual
     (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--filter', default='')
     ap.add_argument('--wino', action='store_true', help='3x3 stride-1 shapes through the Winograd F(2,3) kernel')
     ap.add_argument('--wino2', action='store_true', help='... through the 2-D Winograd F(2x2,3x3) kernel')
+    ap.add_argument('--wino24', action='store_true', help='... Cin > 16 shapes through the F(2x4,3x3) kernel (others as --wino2)')
     ap.add_argument('--wino3', action='store_true', help='... Cin<=32/Cout=32 shapes through the LDS-resident F(2x2,3x3) kernel')
     ap.add_argument('--phase', type=int, default=0, help='loader-wave tuning switch: 8 = idle loader (timing ablation, wrong results), 9 = loader at priority 0')
     ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
@@ -71,12 +72,14 @@ def main():
         w = (np.random.randn(coutg, cing, k, k) / np.sqrt(cing * k * k)).astype(np.float32)
         wino = 0
         if k == 3 and stride == 1:
-            wino = 2 if (args.wino2 or args.wino3) else (1 if args.wino else 0)
+            wino = 2 if (args.wino2 or args.wino3 or args.wino24) else (1 if args.wino else 0)
+            if args.wino24 and cing > 16 and coutg != 33:
+                wino = 4
         if wino and args.wino3 and groups == 1 and cin <= 32 and cout == 32:
             wino = 3
             packed = [packer.pack_wino3(w.astype(np.float64), np.zeros(coutg, np.float32))]
         else:
-            tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights)[wino]
+            tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights, None, packer.winograd24_weights)[wino]
             packed = [packer.pack_conv(tr(w), np.zeros(coutg, np.float32)) for _ in range(groups)]
         wp = torch.from_numpy(np.concatenate([q[0] for q in packed])).cuda()
         bp = torch.from_numpy(np.concatenate([q[1] for q in packed])).cuda()
