@@ -78,8 +78,10 @@ __device__ __forceinline__ float from_h16(unsigned short u) {
 // a: `in`, in_cs, in_coff, Cin, cin8 are the FLOAT VIEW of the 16-bit input (see above; launch_conv_h16 builds it);
 // out / res / out_cs / out_coff / res_cs / res_coff / Cout are in elements of the output type.
 // ONE: every item is a single Cin chunk.
+// RING: depth of the weight-fragment ring for 3x3 kernels (0 = by register budget: 9 units with one n-tile per wave, 3 with
+// two); 3 is enough where the layer's weights stay in the CU's L1 (Cin, Cout <= 32: 18 KiB).
 template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW, bool ONE, bool BF,
-          bool OUTF32>
+          bool OUTF32, int RING = 0>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_kernel(const ConvArgs a, const ConvWork wk) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4;
   constexpr int NCW = WAVES_M * WAVES_N;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
   constexpr int UNITS = SU * TAPS;                  // (step, tap) units per pass
   // weight-fragment ring (L2 latency; a unit is MT*NTW MFMAs of 32 cycles): 9 units deep where the registers allow it
   // (two n-tiles per wave: 72 registers of fragments next to 64 of accumulators and the residual prefetch spill)
-  constexpr int R = TAPS == 1 ? 4 : (NTW >= 2 ? 3 : 9);
+  constexpr int R = TAPS == 1 ? 4 : (RING ? RING : (NTW >= 2 ? 3 : 9));
   constexpr int RA = TAPS == 1 ? 2 : 3;             // activation-fragment ring (LDS latency)
   constexpr int PSTR = 36, PTILE = 32 * PSTR;       // epilogue tile: [32 pixels][32 couts + 4 pad] floats
   constexpr int ESZ = OUTF32 ? 4 : 2;               // bytes per output / residual element
@@ -399,13 +401,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
 }
 
 template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW, bool ONE, bool BF,
-          bool OUTF32>
+          bool OUTF32, int RING = 0>
 static hipError_t launch_h16_impl(const ConvArgs& a, hipStream_t s) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr size_t lds = (2 * (size_t)PH * PW * (CK + 4) + (size_t)WAVES_M * WAVES_N * 32 * 36) * sizeof(float);
   static_assert(lds <= 160 * 1024, "two patch buffers and the epilogue tiles must fit the 160 KiB LDS");
   constexpr int NTHREADS = (WAVES_M * WAVES_N + NLW) * 64;
-  auto kern = conv_h16_kernel<KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW, ONE, BF, OUTF32>;
+  auto kern = conv_h16_kernel<KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW, ONE, BF, OUTF32, RING>;
   static unsigned char init[MAX_DEVICES] = {};
   if (first_use_on_device(init)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -430,12 +432,13 @@ static hipError_t launch_h16_impl(const ConvArgs& a, hipStream_t s) {
 }
 
 // F32OK: the shape also exists with fp32 output (the head exits); the other shapes only ever write 16-bit maps
-template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW, bool F32OK = false>
+template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW, bool F32OK = false,
+          int RING = 0>
 static hipError_t launch_h16(const ConvArgs& a, hipStream_t s) {
   const bool one = (a.cin8 * 8 + CK - 1) / CK < 2;
   const bool bf = a.dtype == ACRMI_DT_BF16;
 #define ACRMI_H16_CASE(ONE_, BF_, F32_) \
-  return launch_h16_impl<KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW, ONE_, BF_, F32_>(a, s)
+  return launch_h16_impl<KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW, ONE_, BF_, F32_, RING>(a, s)
   if (a.out_f32) {
     if constexpr (F32OK) {
       if (one) { if (bf) ACRMI_H16_CASE(true, true, true); ACRMI_H16_CASE(true, false, true); }
@@ -473,10 +476,16 @@ hipError_t launch_conv_h16(ConvArgs a, hipStream_t s) {
   const int nb2 = (a.n_tiles + 1) / 2;
   // template arguments <KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK (floats = 2 elements), NLW>
   if (a.ks == 3 && a.stride == 1) {
-    if (n32) return (small || tiles16 < cus) ? launch_h16<3, 1, 8, 16, 4, 1, 1, 1, 32, 2>(a, s)
-                                             : launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 32, 4>(a, s);
-    return (small || tiles16 * nb2 < cus) ? launch_h16<3, 1, 8, 16, 2, 2, 2, 1, 32, 2, true>(a, s)
-                                          : launch_h16<3, 1, 16, 16, 4, 2, 1, 2, 32, 4, true>(a, s);
+    // One n-tile per wave and per ITEM on the big maps, whatever Cout is: with two n-tiles per wave the weight-fragment
+    // ring is 3 units deep (registers) - shorter than an L2 round trip, the 64- and 128-channel layers then wait for
+    // weight fragments (branch 2: 1.86 -> 1.59 ms per step with the deeper ring) - and 4 m-tiles x 1 n-tile per wave
+    // spills (188..540 bytes of scratch).  The n-blocks of a tile are consecutive work items of one XCD band: the
+    // patch is fetched from HBM once and re-read from L2.
+    if (small || tiles16 * (n32 ? 1 : nb2) < cus)
+      return n32 ? launch_h16<3, 1, 8, 16, 4, 1, 1, 1, 32, 2>(a, s) : launch_h16<3, 1, 8, 16, 2, 2, 2, 1, 32, 2, true>(a, s);
+    // (measured and dropped: 32x16-pixel items with a 16-float chunk and a 3-unit ring for the Cin, Cout <= 32 layers -
+    // 4 m-tiles per wave spill 104 bytes in the single-chunk variant, branch 0 went from 3.95 to 4.17 ms per step)
+    return launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 32, 4, true>(a, s);
   }
   if (a.ks == 3 && a.stride == 2) {
     if (n32 || tiles8 * nb2 < cus) return launch_h16<3, 2, 8, 16, 4, 1, 1, 1, 16, 4>(a, s);
