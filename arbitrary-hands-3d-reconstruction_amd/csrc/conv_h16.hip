@@ -79,7 +79,11 @@ __device__ __forceinline__ float from_h16(unsigned short u) {
 // out / res / out_cs / out_coff / res_cs / res_coff / Cout are in elements of the output type.
 // ONE: every item is a single Cin chunk.
 // RING: depth of the weight-fragment ring for 3x3 kernels (0 = by register budget: 9 units with one n-tile per wave, 3 with
-// two); 3 is enough where the layer's weights stay in the CU's L1 (Cin, Cout <= 32: 18 KiB).
+// two).  RING = -1 (3x3, single-chunk items of <= 2 steps, one n-tile, one group): the layer's whole weight set - 9 taps x 2
+// steps = 18 fragments = 72 registers - is loaded ONCE per wave and stays in registers for the launch.  That is HRNet
+// branch 0 (32 -> 32 at 128x128, 64 launches per step): with the ring, 4 waves x 18 KiB of fragments per item went through
+// the CU's L1 (64 B/clk: as long as the item's 1152 cycles of MFMAs) next to the loader waves' streaming activation loads
+// that evict them - stamps: 5.5k cycles of "MFMA phase" per item.
 template <int KS, int S, int TH, int TW, int WAVES_M, int MT, int WAVES_N, int NTW, int CK, int NLW, bool ONE, bool BF,
           bool OUTF32, int RING = 0>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_kernel(const ConvArgs a, const ConvWork wk) {
@@ -88,12 +92,16 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
   constexpr int TAPS = KS * KS;
   constexpr int BUF = PH * PW * CP;
   constexpr int SPC = CK / 8;                       // 16-element steps per full chunk
-  constexpr int SU = TAPS == 1 ? 4 : 1;             // steps per statically unrolled pass
+  constexpr bool WREG = RING < 0;                    // the layer's weights live in registers
+  constexpr int SU = TAPS == 1 ? 4 : (WREG ? 2 : 1); // steps per statically unrolled pass
   constexpr int UNITS = SU * TAPS;                  // (step, tap) units per pass
   // weight-fragment ring (L2 latency; a unit is MT*NTW MFMAs of 32 cycles): 9 units deep where the registers allow it
   // (two n-tiles per wave: 72 registers of fragments next to 64 of accumulators and the residual prefetch spill)
-  constexpr int R = TAPS == 1 ? 4 : (RING ? RING : (NTW >= 2 ? 3 : 9));
-  constexpr int RA = TAPS == 1 ? 2 : 3;             // activation-fragment ring (LDS latency)
+  constexpr int R = TAPS == 1 ? 4 : (WREG ? 2 * TAPS : (RING ? RING : (NTW >= 2 ? 3 : 9)));
+  static_assert(!WREG || (ONE && TAPS == 9 && NTW == 1 && WAVES_N == 1 && CK == 16), "register-resident weights: 3x3, one chunk of <= 2 steps, one n-tile");
+  // activation-fragment ring (LDS latency).  Measured: 6 / 9 deep instead of 3 changes nothing (the 195 cycles per
+  // 64-cycle unit in the stamps are not LDS latency) and spills the 1x1 fp32-output kernels
+  constexpr int RA = TAPS == 1 ? 2 : 3;
   constexpr int PSTR = 36, PTILE = 32 * PSTR;       // epilogue tile: [32 pixels][32 couts + 4 pad] floats
   constexpr int ESZ = OUTF32 ? 4 : 2;               // bytes per output / residual element
   constexpr int NGQ = OUTF32 ? 4 : 2;               // store rounds per 32-pixel tile (8 / 16 pixels each)
@@ -277,8 +285,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
 #pragma unroll
         for (int m = 0; m < MT; ++m)
           act[ra][m] = *reinterpret_cast<const f32x4*>(ps_ + aoff[m] + ((ta / KS) * PW + ta % KS) * CP + sa * 8);
-        const int un = u + R, tn = un % TAPS, sn = un / TAPS;
-        load_w(r, wsc, tn, c0 / 8 + s + sn);
+        if constexpr (!WREG) {
+          const int un = u + R, tn = un % TAPS, sn = un / TAPS;
+          load_w(r, wsc, tn, c0 / 8 + s + sn);
+        }
       }
     };
     if (FIRST) pass(0, std::true_type());
@@ -377,8 +387,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
       // weight fragments of the first units of the item's next n-block / of the next item
       __builtin_amdgcn_sched_barrier(0);
       const WStream wnext = nb + 1 < nbn ? wstream(w, nb + 1) : wsn;
+      if constexpr (!WREG) {
 #pragma unroll
-      for (int u = 0; u < R; ++u) load_w(u, wnext, u % TAPS, u / TAPS);
+        for (int u = 0; u < R; ++u) load_w(u, wnext, u % TAPS, u / TAPS);
+      }
       wsc = wnext;
       if (stamp && ns_ < 60) a.dbg[ns_++] = clock64();
     }
@@ -449,8 +461,12 @@ static hipError_t launch_h16(const ConvArgs& a, hipStream_t s) {
     }
   }
   if (one) { if (bf) ACRMI_H16_CASE(true, true, false); ACRMI_H16_CASE(true, false, false); }
-  if (bf) ACRMI_H16_CASE(false, true, false);
-  ACRMI_H16_CASE(false, false, false);
+  if constexpr (RING < 0) {
+    return hipErrorInvalidValue;      // register-resident weights exist for single-chunk items only
+  } else {
+    if (bf) ACRMI_H16_CASE(false, true, false);
+    ACRMI_H16_CASE(false, false, false);
+  }
 #undef ACRMI_H16_CASE
 }
 
@@ -485,6 +501,9 @@ hipError_t launch_conv_h16(ConvArgs a, hipStream_t s) {
       return n32 ? launch_h16<3, 1, 8, 16, 4, 1, 1, 1, 32, 2>(a, s) : launch_h16<3, 1, 8, 16, 2, 2, 2, 1, 32, 2, true>(a, s);
     // (measured and dropped: 32x16-pixel items with a 16-float chunk and a 3-unit ring for the Cin, Cout <= 32 layers -
     // 4 m-tiles per wave spill 104 bytes in the single-chunk variant, branch 0 went from 3.95 to 4.17 ms per step)
+    // Cin <= 32 elements, Cout <= 32, one group: the layer's 18 weight fragments stay in registers (RING = -1)
+    if (n32 && a.groups == 1 && a.cin8 <= 2 && !a.out_f32 && conv_forced_cfg() != 902)
+      return launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 16, 4, false, -1>(a, s);
     return launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 32, 4, true>(a, s);
   }
   if (a.ks == 3 && a.stride == 2) {

@@ -159,11 +159,24 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
         conv_ms = sum(p['ms'] for p in prof if p['kind'] in (pkg('_lib').OP_CONV, pkg('_lib').OP_STEM))
         total_ms = sum(p['ms'] for p in prof)
         flops = sum(p['flops'] for p in prof) * B
-        act_bytes = None
+        # algorithmic HBM bytes of the conv ops: input + output (+ residual) once, in their storage types
+        ops_, bufs_ = eng.program['ops'], eng.program['bufs']
+        esz = lambda b: 2 if bufs_[b][4] else 4
+        conv_bytes = 0
+        for p in prof:
+            o = ops_[p['idx']]
+            if p['kind'] == pkg('_lib').OP_CONV:
+                conv_bytes += B * (bufs_[o.in_buf][0] * bufs_[o.in_buf][1] * o.cin * o.groups * esz(o.in_buf) +
+                                   bufs_[o.out_buf][0] * bufs_[o.out_buf][1] * o.cout * o.groups * esz(o.out_buf) *
+                                   (2 if o.res_buf >= 0 else 1))
         r = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
              'dtype': {'fp16': 'f16', 'bf16': 'bf16'}[prec] + ' storage, f32 accumulate (v_mfma_f32_32x32x16)',
              'all_conv_ms_single_stream': round(conv_ms, 3), 'all_ops_ms_single_stream': round(total_ms, 3),
-             'mfma_tflops_single_stream': round(flops / (total_ms * 1e-3) / 1e12, 1), 'mfma_peak_tflops': 2500.0}
+             'mfma_tflops_single_stream': round(flops / (total_ms * 1e-3) / 1e12, 1), 'mfma_peak_tflops': 2500.0,
+             'roofline': {'bound': 'hbm', 'achieved': round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                          'frac': round(conv_bytes / (conv_ms * 1e-3) / 1e9 / 8000.0, 4),
+                          'definition': 'algorithmic bytes of all conv launches (in + out + residual once, storage types) / their '
+                                        'single-stream time; at 16x the fp32 matrix rate the layers are HBM / L2 bound'}}
         if oracle is not None:
             r['parity'] = parity(eng, oracle)
         res[prec] = r
@@ -174,7 +187,7 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
     return res
 
 
-def live_pmc(batch, timeout_s=300):
+def live_pmc(batch, timeout_s=300, precision='fp32'):
     """the PMC figures of the bench line measured in THIS run instead of read from profiles/ - bench.py
     re-executes itself (one warm-up + one step, one context, one stream) under `rocprofv3 --kernel-trace --pmc ...`, in
     two passes because FETCH_SIZE and WRITE_SIZE do not fit the TCC's counter slots together (MI355X_MICROARCH.md); no
@@ -200,7 +213,7 @@ def live_pmc(batch, timeout_s=300):
         for tag, counters in passes:
             out = os.path.join(tmp, tag)
             cmd = [exe, '--output-format', 'csv', '--kernel-trace', '--pmc'] + counters + ['-d', out, '-o', 'p', '--', sys.executable,
-                   os.path.join(ROOT, 'bench.py'), '--pmc-child', '--batch', str(batch)]
+                   os.path.join(ROOT, 'bench.py'), '--pmc-child', '--batch', str(batch), '--precision', precision]
             r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None
@@ -243,14 +256,14 @@ def live_pmc(batch, timeout_s=300):
                       'step, batch %d, one context, one stream); FETCH_SIZE x 2 (gfx950), WRITE_SIZE exact' % batch}
 
 
-def pmc_child(batch):
+def pmc_child(batch, precision='fp32'):
     """The workload live_pmc() profiles: the fp32 headline program, one warm-up + one step on one stream."""
     synth = pkg('synth')
     tables = synth.make_mano_tables(seed=1)
     tables['left']['shapedirs'] = tables['left']['shapedirs'].copy()
     tables['left']['shapedirs'][:, 0, :] *= -1
     eng = pkg('engine').Engine(0)
-    eng.load_state_dict(synth.make_state_dict(seed=0), max_batch=batch)
+    eng.load_state_dict(synth.make_state_dict(seed=0), max_batch=batch, precision=precision)
     eng.load_mano(tables)
     eng.set_lanes(1)
     frames = torch.from_numpy(synth.make_frames(batch, seed=0, structured=False)).cuda()
@@ -337,13 +350,14 @@ def main():
     ap.add_argument('--no-reduced-precision', action='store_true', help='skip the separately reported fp16 / bf16 programs')
     ap.add_argument('--no-pmc', action='store_true', help='do not re-run one step under rocprofv3 --pmc; roofline.traffic / mfma_busy_pmc then come from profiles/')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--precision', default='fp32', help='fp32 = the headline (BASELINE.json configs[2]); fp16 / bf16 run the 16-bit program as the timed workload - for profiling runs (tools/profile_round.sh), NOT the headline: the line then says so in dtype / config')
     ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default, 1 per context with --pipeline >= 2)')
     ap.add_argument('--pipeline', type=int, default=2, help='contexts taking batches in turn on their own streams (engine.EnginePool): the tail of one batch overlaps the head of the next; 1 = one context')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
     args = ap.parse_args()
 
     if args.pmc_child:
-        pmc_child(args.batch)
+        pmc_child(args.batch, args.precision)
         return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -374,7 +388,7 @@ def main():
     if use_dist:
         npipe = min(npipe, 2)                   # ShardedRunner double-buffers its result sets
     eng = pkg('engine').Engine(local_rank)
-    eng.load_state_dict(sd, max_batch=B)
+    eng.load_state_dict(sd, max_batch=B, precision=args.precision)
     eng.load_mano(tables)
     eng.set_lanes(args.lanes)
     frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False)).cuda()   # resident in HBM
@@ -472,13 +486,13 @@ def main():
         out = {'metric': 'frames/sec (2-hand mesh) at 512x512 batch-64; vertex L2 vs ref', 'value': round(fps, 2),
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32', 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
-               'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, fp32',
+               'dtype': {'fp32': 'f32', 'fp16': 'f16 storage / f32 accumulate (NOT the headline precision)', 'bf16': 'bf16 storage / f32 accumulate (NOT the headline precision)'}[args.precision], 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
+               'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, %s' % args.precision,
                           'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
                           'contexts_in_turn': npipe,
                           'gflop_per_frame': GFLOP_PER_FRAME},
                'roofline': roofline}
-        if world == 1 and not args.no_point_heads:
+        if world == 1 and not args.no_point_heads and args.precision == 'fp32':
             setter = (lambda on: pool.configure(lambda e: e.set_point_heads(on))) if pool is not None else eng.set_point_heads
             out['point_heads'] = point_heads_rate(setter, run_steps, B, args.steps, args.warmup)
         if world == 1 and not use_dist and pool is not None and not args.no_latency:
@@ -506,7 +520,7 @@ def main():
                 pool = None
             eng.set_lanes(0)
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
-        if world == 1 and not use_dist and not args.no_pmc:
+        if world == 1 and not use_dist and not args.no_pmc and args.precision == 'fp32':
             # counters of THIS box, THIS run (the committed profiles/ figures stay as the fallback, labelled as such)
             live = live_pmc(B)
             if live is not None:
@@ -521,7 +535,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             oracle, out['cpu_baseline'] = cpu_baseline(sd, tables)
             out['parity'] = parity(eng, oracle)
-        if world == 1 and not use_dist and not args.no_reduced_precision:
+        if world == 1 and not use_dist and not args.no_reduced_precision and args.precision == 'fp32':
             if pool is not None:
                 pool.close(keep_first=True)
                 pool = None

@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--wino2', action='store_true', help='... through the 2-D Winograd F(2x2,3x3) kernel')
     ap.add_argument('--wino24', action='store_true', help='... Cin > 16 shapes through the F(2x4,3x3) kernel (others as --wino2)')
     ap.add_argument('--wino3', action='store_true', help='... Cin<=32/Cout=32 shapes through the LDS-resident F(2x2,3x3) kernel')
+    ap.add_argument('--h16', default='', help="'fp16' | 'bf16': the 16-bit direct kernels (conv_h16.hip) on 16-bit tensors")
     ap.add_argument('--phase', type=int, default=0, help='loader-wave tuning switch: 8 = idle loader (timing ablation, wrong results), 9 = loader at priority 0')
     ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
     args = ap.parse_args()
@@ -64,6 +65,42 @@ def main():
         if args.filter not in name:
             continue
         cing, coutg = cin // groups, cout // groups
+        if args.h16:
+            td = torch.float16 if args.h16 == 'fp16' else torch.bfloat16
+            dt = packer.PRECISIONS[args.h16]
+            cs_in, cs_out = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+            x = torch.randn(B, H, W, cs_in, device='cuda').to(td)
+            Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+            out = torch.empty(B, Ho, Wo, cs_out, device='cuda', dtype=td)
+            res = torch.randn(B, Ho, Wo, cs_out, device='cuda').to(td) if use_res else None
+            w = (np.random.randn(coutg, cing, k, k) / np.sqrt(cing * k * k))
+            packed = [packer.pack_conv_h16(w, np.zeros(coutg, np.float32), dt) for _ in range(groups)]
+            wp = torch.from_numpy(np.concatenate([q[0] for q in packed]).view(np.int16)).cuda()
+            bp = torch.from_numpy(np.concatenate([q[1] for q in packed])).cuda()
+
+            def launch():
+                rc = lib.acrmi_conv2d_h16(p(x), B, H, W, cs_in, 0, cing, p(wp), p(bp), 0, p(res), cs_out, 0, p(out), cs_out, 0,
+                                          coutg, k, stride, 1, groups, dt, 0, None)
+                assert rc == 0, lib.acrmi_last_error(None)
+            for _ in range(3):
+                launch()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                launch()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            flops = 2.0 * B * Ho * Wo * coutg * cing * k * k * groups
+            byts = 2.0 * B * (H * W * cin + Ho * Wo * cout * (2 if use_res else 1))
+            print('%-28s %8.3f ms  %6.1f TF  %6.2f TB/s(min traffic)' % (name, ms, flops / ms / 1e9, byts / ms / 1e9), flush=True)
+            if args.stamps:
+                lib.acrmi_tune(1, 1)
+                launch()
+                lib.acrmi_tune(2, 0)
+                lib.acrmi_tune(1, 0)
+            continue
         cs_in, cs_out = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
         x = torch.randn(B, H, W, cs_in, device='cuda')
         Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
