@@ -1,0 +1,104 @@
+"""CPU checks of the round-3 lowering paths (no GPU): the op-list interpreter (oracle/program.py) is pinned on the fp32
+HRNet-W32 program to the reference-pinned oracle; the 16-bit / HRNet-W48 lowerings are structurally sound; the 16-bit
+weight packing and rounding are what conv_h16_kernel expects."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import acr_net, program as oprog
+
+
+@pytest.fixture(scope='module')
+def frame():
+    return torch.from_numpy(pkg('synth').make_frames(1, seed=0))
+
+
+def test_interpreter_reads_the_fp32_program_like_the_pinned_oracle(synth_sd, frame):
+    """oracle/program.py on the fp32 W32 program == oracle/acr_net.py (itself pinned to the real reference by
+    tests/test_oracle_pinned.py) on every head map: this pins the interpreter's reading of the op list - strides, channel
+    slices, groups, residuals, per-frame bias, the composed exits - before it serves as own-oracle of the 16-bit programs."""
+    torch.set_num_threads(8)
+    prog = pkg('packer').lower(synth_sd, keep_weights=True, point_heads=False)
+    got = oprog.run_program(prog, frame).head_maps()
+    with torch.no_grad():
+        ref = acr_net.network(synth_sd, frame)
+    for k in ref:
+        err, scale = float((got[k] - ref[k]).abs().max()), float(ref[k].abs().max())
+        assert err < 2e-5 * max(1.0, scale), (k, err, scale)
+
+
+def test_16bit_interpreter_stays_within_quantisation_noise(synth_sd, frame):
+    """The fp16 program, interpreted: rounding once per layer costs ~1e-3 relative per layer; through the network the head
+    maps stay within a few 1e-3 of the fp32 oracle's (the bound the GPU test compares the kernels against)."""
+    torch.set_num_threads(8)
+    prog = pkg('packer').lower(synth_sd, keep_weights=True, precision='fp16')
+    assert prog['precision'] == 'fp16' and prog['width'] == 32
+    got = oprog.run_program(prog, frame).head_maps()
+    with torch.no_grad():
+        ref = acr_net.network(synth_sd, frame)
+    for k in ref:
+        err, scale = float((got[k] - ref[k]).abs().max()), float(ref[k].abs().max())
+        assert 1e-5 < err < 1e-2 * max(1.0, scale), (k, err, scale)
+
+
+@pytest.mark.parametrize('precision,width', [('fp16', 32), ('bf16', 32), ('fp32', 48), ('fp16', 48)])
+def test_lowering_of_16bit_and_w48_programs_is_consistent(precision, width):
+    packer, synth, L = pkg('packer'), pkg('synth'), pkg('_lib')
+    sd = synth.make_state_dict(seed=0, width=width)
+    prog = packer.lower(sd, precision=precision)
+    dt = packer.PRECISIONS[precision]
+    bufs, ops = prog['bufs'], prog['ops']
+    assert prog['width'] == width and {b[4] for b in bufs} <= {0, dt}
+    hl = prog['heads']
+    for b in (hl.center_buf[0], hl.center_buf[1], hl.params_buf[0], hl.params_buf[1], hl.prior_buf[0], hl.prior_buf[1], hl.segm_buf):
+        assert bufs[b][4] == 0                                         # head maps stay fp32 (acr/model.py:56-62 .float())
+    assert bufs[hl.backbone_buf][4] == dt and bufs[hl.backbone_buf][2] >= width + 2
+    for b in bufs:
+        assert b[2] % (8 if b[4] else 4) == 0                          # 16-byte vectors
+    n_conv = 0
+    for o in ops:
+        if o.kind == L.OP_CONV:
+            n_conv += 1
+            idt, odt = bufs[o.in_buf][4], bufs[o.out_buf][4]
+            assert idt == dt and odt in (dt, 0)
+            assert o.res_buf < 0 or bufs[o.res_buf][4] == odt         # a residual has the type of the output
+            if dt:
+                assert (o.flags & 7) == 0                              # 16-bit programs: direct kernel only
+        assert o.kind != L.OP_POINTHEADS or (dt == 0 and width == 32)
+    assert n_conv >= 300
+    if width == 48:
+        assert sd['backbone.stage4.0.branches.3.0.conv1.weight'].shape == (384, 384, 3, 3)
+        assert sd['l_final_layers.1.0.0.weight'].shape[1] == 50
+
+
+def test_pack_conv_h16_layout_and_rounding():
+    packer = pkg('packer')
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(40, 20, 3, 3))
+    for name, dt, td in (('fp16', packer.DT_F16, torch.float16), ('bf16', packer.DT_BF16, torch.bfloat16)):
+        bits, bp = packer.pack_conv_h16(w, np.arange(40, dtype=np.float32), dt)
+        assert bits.dtype == np.uint16 and bits.size == 9 * 2 * 2 * 64 * 8 and bp.size == 64      # 2 steps of 16, 2 n-tiles
+        vals = torch.from_numpy(bits.view(np.int16).copy()).view(td).float().numpy().reshape(3, 3, 2, 2, 64, 8)
+        want = torch.from_numpy(w.astype(np.float32)).to(td).float().numpy()                       # torch's nearest-even rounding
+        # [ky][kx][s][nt][lane][e]: cout = nt*32 + (lane & 31), ci = 16 s + 8 (lane >> 5) + e
+        for (ky, kx, s, nt, lane, e) in ((0, 0, 0, 0, 0, 0), (1, 2, 1, 1, 37, 3), (2, 1, 0, 1, 7, 7), (1, 1, 1, 0, 63, 1)):
+            co, ci = nt * 32 + (lane & 31), 16 * s + 8 * (lane >> 5) + e
+            exp = want[co, ci, ky, kx] if co < 40 and ci < 20 else 0.0
+            assert vals[ky, kx, s, nt, lane, e] == exp, (name, ky, kx, s, nt, lane, e)
+        assert np.array_equal(packer.round_to(w, dt), want)
+
+
+def test_planted_center_peaks_are_where_they_were_planted(frame):
+    """synth.plant_center_peaks: the oracle's center maps peak exactly at the planted interior pixels (the fixture
+    e2e_interior.npz is the real reference's view of the same checkpoints)."""
+    import cases
+    from oracle import decode as odec
+    torch.set_num_threads(8)
+    sd = cases.interior_state_dict(pkg('synth'), 'mid')
+    with torch.no_grad():
+        maps = acr_net.network(sd, frame)
+    s = odec.decode(maps)
+    _, lp, rp = cases.INTERIOR_CASES['mid']
+    assert s['flag'].tolist() == [[True, True]]
+    assert s['flat_ind'].tolist() == [[lp[0] * 64 + lp[1], rp[0] * 64 + rp[1]]]
