@@ -92,7 +92,10 @@ struct NoHook {
 // PREP_SLACK: compute the next item's geometry in the slack before the barrier (direct kernels: their compute waves
 // reach the barrier late) instead of right before its first request (Winograd kernel: there the loader is what the
 // barrier waits for, and anything ahead of it delays every wave).
-template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook, bool PREP_SLACK = true, int PRIO = 3>
+// EXTRA: workgroup barriers the compute waves execute inside an item's epilogue, BEHIND the barrier that ends the
+// item's last chunk (conv_wino24_kernel parks its tiles in two rounds); the loader waves have to arrive at them too.
+// Seen from here that barrier is the one behind the write of the NEXT item's first chunk (or the final one).
+template <int KS, int S, int TH, int TW, int CK, int NLW, class Hook = NoHook, bool PREP_SLACK = true, int PRIO = 3, int EXTRA = 0>
 __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk, float* lds, int ltid, int ktotal,
                                           int cin_pad, Hook hook = Hook()) {
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, CP = CK + 4, PAD = KS / 2;
@@ -204,6 +207,12 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
     if constexpr (PREP_SLACK) prepare(prep);
     // barrier k: buffer k&1 is full; the compute waves finished reading it two chunks ago
     __syncthreads();
+    if constexpr (EXTRA > 0) {
+      if (k > 0 && c0 == 0) {        // (uniform) chunk k opens an item: the previous item's epilogue runs behind this barrier
+#pragma unroll
+        for (int e = 0; e < EXTRA; ++e) __syncthreads();
+      }
+    }
     c0 += CK;
     if (c0 >= cin_pad) { c0 = 0; w += gridDim.x; }
   };
@@ -232,6 +241,12 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
     }
   }
   __syncthreads();   // matches the compute waves' final barrier
+  if constexpr (EXTRA > 0) {
+    if (ktotal > 0) {
+#pragma unroll
+      for (int e = 0; e < EXTRA; ++e) __syncthreads();
+    }
+  }
 }
 
 

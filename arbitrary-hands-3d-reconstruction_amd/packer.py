@@ -179,12 +179,14 @@ def use_winograd(k, stride):
 WINOGRAD_LDS = True
 
 
-# F(2x4,3x3) (algo 4, conv_wino24.inc: F(4,3) along x, 1.33x fewer MFMAs than F(2x2,3x3), ~10x its round-off) for the
-# layers with Cin >= 32 on maps at least one 32-pixel tile wide.  OFF: built, parity-green (19 kernel cases) and measured
-# in round 3 - with the 16-channel chunks its LDS budget forces (two 10x34 patches + 16 parked tiles) an item spends 44 %
-# of its cycles in MFMAs against conv_wino2_kernel's 64 %, which eats the 1.33x: 0.112 vs 0.108 ms (64->64 @64x64), 0.105
-# vs 0.099 ms (128->128 @32x32) at batch 64 (tools/conv_bench.py --wino24).
-WINOGRAD_24 = False
+# F(2x4,3x3) (algo 4, conv_wino24.inc: F(2,3) along y, F(4,3) along x - 1.33x fewer MFMAs than F(2x2,3x3)) for the layers
+# with Cin > 32 on maps that tile into 8x32-pixel items (branches 1 and 2, the head towers, layer1's 3x3, the contact and
+# transition convs: 133 launches).  Round 3: first built with 16-channel chunks (no gain: 44 % of an item's cycles in MFMAs),
+# then with 32-channel chunks and the exchange in two rounds: 0.104 vs 0.108 ms (64->64 @64x64), 0.092 vs 0.099
+# (128->128 @32x32), 0.388 vs 0.413 (64->64 @128x128) per launch at batch 64; whole path 1631 -> 1662 frames/s on the same
+# box.  Round-off, hostile checkpoint: worst layer 1.2e-6 of its largest output (F(2x2): 9.5e-7), vertices 2.9e-7 m.
+# ACRMI_WINO24=0 lowers those layers to F(2x2,3x3) again (A/B runs).
+WINOGRAD_24 = __import__('os').environ.get('ACRMI_WINO24', '1') != '0'
 
 
 def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False):
@@ -194,7 +196,7 @@ def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False):
     if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
             and not per_frame_bias):
         return 3
-    if WINOGRAD_2D and WINOGRAD_24 and cin >= 32 and cout != 33 and wo % 32 == 0 and ho % 8 == 0:
+    if WINOGRAD_2D and WINOGRAD_24 and cin > 32 and cout != 33 and wo % 32 == 0 and ho % 8 == 0:
         return 4
     return 2 if WINOGRAD_2D else 1
 

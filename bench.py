@@ -30,8 +30,8 @@ PKG = 'arbitrary-hands-3d-reconstruction_amd'
 
 GFLOP_PER_FRAME = 102.1          # BASELINE.md §3 / SURVEY.md §8d (2*MAC, direct conv + bmm + linear)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
-DOMINANT = 'conv_wino2_kernel + conv_wino3_kernel (3x3 stride-1 convolutions, Winograd F(2x2,3x3) on fp32 MFMA)'
-MFMA_REDUCTION = {'winograd_f2x2_3x3': 2.25, 'winograd_f2x2_3x3_lds': 2.25, 'winograd_f23x': 1.5}   # algorithmic MACs per executed MFMA MAC
+DOMINANT = 'conv_wino24_kernel + conv_wino3_kernel + conv_wino2_kernel (3x3 stride-1 convolutions: Winograd F(2x4,3x3) / F(2x2,3x3) on fp32 MFMA)'
+MFMA_REDUCTION = {'winograd_f2x2_3x3': 2.25, 'winograd_f2x2_3x3_lds': 2.25, 'winograd_f23x': 1.5, 'winograd_f2x4_3x3': 3.0}   # algorithmic MACs per executed MFMA MAC
 PROFILE_TAGS = ('r03', 'r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
 
 
@@ -458,7 +458,8 @@ def main():
             tpath = os.path.join(ROOT, 'profiles', '%s_hbm_traffic.json' % tag)
             if traffic is None and os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = round(json.load(f)['kernels'].get('conv_wino2_kernel', {}).get('hbm_bytes_per_launch', 0)) or None
+                    kk = json.load(f)['kernels']
+                    traffic = round((kk.get('conv_wino24_kernel') or kk.get('conv_wino2_kernel') or {}).get('hbm_bytes_per_launch', 0)) or None
                 traffic_src = 'profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)' % tag
             bpath = os.path.join(ROOT, 'profiles', '%s_pmc_mfma.json' % tag)
             if busy is None and os.path.exists(bpath):
@@ -471,13 +472,13 @@ def main():
         # algorithmic figure (direct-convolution FLOPs / time) is kept next to it as algorithmic_*.
         roofline = {'bound': 'mfma', 'achieved': round(executed_tf, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(executed_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                    'frac_definition': 'EXECUTED fp32 MFMA FLOP of the dominant kernels / launch time / peak (Winograd F(2x2,3x3) '
-                                       'executes 2.25x fewer MACs than the direct form; the algorithmic 2*MAC figure is algorithmic_frac)',
+                    'frac_definition': 'EXECUTED fp32 MFMA FLOP of the dominant kernels / launch time / peak (Winograd F(2x4,3x3) / '
+                                       'F(2x2,3x3) execute 3x / 2.25x fewer MACs than the direct form; the algorithmic 2*MAC figure is algorithmic_frac)',
                     'traffic': traffic, 'traffic_source': traffic_src,
                     'kernel': DOMINANT, 'launches_per_step': len(dom),
                     'algorithmic_achieved': round(achieved, 2),
                     'algorithmic_frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    'winograd_mac_reduction': 2.25, 'mfma_busy_pmc': busy,
+                    'winograd_mac_reduction': {'f2x4_3x3': 3.0, 'f2x2_3x3': 2.25}, 'mfma_busy_pmc': busy,
                     'avg_launch_ms': round(dom_ms / max(1, len(dom)), 4),
                     'algorithmic_gflop_per_launch': round(dom_flops / max(1, len(dom)) / 1e9, 2),
                     'share_of_step_ms': round(dom_ms / total_ms, 3),
@@ -524,7 +525,10 @@ def main():
             # counters of THIS box, THIS run (the committed profiles/ figures stay as the fallback, labelled as such)
             live = live_pmc(B)
             if live is not None:
-                t2 = live['traffic'].get('conv_wino2_kernel', {}).get('hbm_bytes_per_launch')
+                fam = {k: v for k, v in live['traffic'].items() if 'wino' in k}
+                top = max(fam, key=lambda k: fam[k]['launches_profiled']) if fam else None      # the family's most-launched kernel
+                t2 = fam[top]['hbm_bytes_per_launch'] if top else None
+                out['roofline']['traffic_kernel'] = top
                 out['roofline']['traffic'] = t2 or out['roofline']['traffic']
                 out['roofline']['traffic_source'] = live['source'] if t2 else out['roofline']['traffic_source']
                 out['roofline']['traffic_per_kernel'] = live['traffic']

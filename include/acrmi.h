@@ -193,7 +193,7 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
  * 2 = Winograd F(2x2,3x3) (3x3 stride 1 only; w_packed = pack_conv(winograd2d_weights(w)));
  * 3 = Winograd F(2x2,3x3) with the layer's taps resident in LDS (groups 1, Cin <= 32, Cout = 32, H % 8 == 0,
  *     W % 16 == 0; w_packed = pack_wino3(w), 64 KiB);
- * 4 = Winograd F(2x4,3x3): F(2,3) along y, F(4,3) along x (3x3 stride 1, Cin > 16; w_packed =
+ * 4 = Winograd F(2x4,3x3): F(2,3) along y, F(4,3) along x (3x3 stride 1, Cin > 32; w_packed =
  *     pack_conv(winograd24_weights(w)), 4x6 taps). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,

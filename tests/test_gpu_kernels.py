@@ -136,12 +136,13 @@ def test_conv2d_winograd2d_matches_torch(ops, case):
         assert out[..., cout:].abs().max().item() == 0.0
 
 
-WINO24_CASES = [c for c in WINO2D_CASES if c[1] // c[7] > 16 and c[2] != 33] + [
+WINO24_CASES = [c for c in WINO2D_CASES if c[1] // c[7] > 32 and c[2] != 33] + [
     (2, 64, 64, 64, 64, 3, 1, 1, True, True),        # branch 1: 4 chunks of 16 channels, 2 n-tiles
     (2, 128, 128, 32, 32, 3, 1, 1, True, False),     # branch 2: one 32-pixel tile column, 8 chunks
-    (1, 32, 64, 8, 32, 3, 1, 1, False, False),       # exactly two chunks, one tile
-    (1, 40, 64, 16, 64, 3, 1, 1, True, True),        # 2.5 chunks: the last chunk is a single (tail) step
-    (1, 24, 16, 11, 45, 3, 1, 1, True, True),        # 1.5 chunks, ragged tile, Cout < 32
+    (1, 64, 64, 8, 32, 3, 1, 1, False, False),       # exactly two chunks, one tile
+    (1, 40, 64, 16, 64, 3, 1, 1, True, True),        # 1.25 chunks: the last chunk is a single (tail) step
+    (1, 72, 16, 11, 45, 3, 1, 1, True, True),        # 2.25 chunks, ragged tile, Cout < 32
+    (3, 64, 96, 24, 96, 3, 1, 1, True, True),        # several items per workgroup with a tiny grid? 27 tiles x 3 n-tiles
     (2, 128, 128, 32, 32, 3, 1, 2, True, True),      # groups
 ]
 
