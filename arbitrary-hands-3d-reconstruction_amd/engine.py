@@ -343,6 +343,7 @@ class EnginePool(object):
         if self._raw:
             with torch.cuda.device(self.device):
                 torch.cuda.synchronize()
+            self._inflight = []          # every batch has run: the tensors the tickets kept alive may go
             self.streams = []
             L = _lib.lib()
             for st in self._raw:

@@ -392,6 +392,45 @@ def test_engine_pool_batches_equal_single_context(synth_sd, mano_tables):
     eng.close()
 
 
+def test_engine_pool_keeps_host_offsets_and_temporaries_alive(synth_sd, mano_tables):
+    """two submits with DIFFERENT host offsets and temporary frame tensors are pipelined before anything is
+    collected, the tickets are released at once (as parallel.ShardedRunner does) and the caller's stream allocates and
+    overwrites new tensors meanwhile: the device copies of `offsets` / `img` the queued batches read must stay alive
+    until the batches have run (EnginePool keeps released tickets referenced until their event has completed)."""
+    t = {k: dict(v) for k, v in mano_tables.items()}
+    t['left']['shapedirs'] = t['left']['shapedirs'].copy()
+    t['left']['shapedirs'][:, 0, :] *= -1
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=8)
+    eng.load_mano(t)
+    pool = pkg('engine').EnginePool(0, n=2)
+    pool.load_state_dict(synth_sd, max_batch=8)
+    pool.load_mano(t)
+    frames = [pkg('synth').make_frames(8, seed=60 + i, structured=True) for i in range(2)]
+    offs = [torch.tensor([[512., 512., 0, 0, 0, 0, 0, 0, 0, 0]] * 8),
+            torch.tensor([[1920., 1920., 0, 0, 0, 0, 420, 0, 420, 0]] * 8)]
+    want = [eng.forward(torch.from_numpy(f).cuda(), offsets=o, project=True)['pj2d_org'].clone() for f, o in zip(frames, offs)]
+    torch.cuda.synchronize()
+    outs, events = [], []
+    for f, o in zip(frames, offs):
+        tk = pool.submit(torch.from_numpy(f).cuda().flip(0).flip(0).contiguous(), offsets=o, project=True)   # temporaries
+        outs.append(tk['out'])
+        events.append(pool.release(tk))
+        del tk
+        for _ in range(4):        # the caller's stream reuses whatever the allocator believes is free
+            junk = torch.full((8, 10), float('nan'), device='cuda')
+            junk2 = torch.zeros(8, 512, 512, 3, dtype=torch.uint8, device='cuda')
+            del junk, junk2
+    for e in events:
+        torch.cuda.current_stream().wait_event(e)
+    torch.cuda.synchronize()
+    for w, g in zip(want, outs):
+        assert torch.equal(w, g['pj2d_org'])
+    assert float((want[0] - want[1]).abs().max()) > 1.0          # the two offsets rows really differ in the result
+    pool.close()
+    eng.close()
+
+
 def test_malformed_programs_are_rejected(synth_sd):
     """acrmi_set_program validates buffer ids (incl. FUSESUM terms and the head layout), weight offsets
     and channel slices - ACRMI_EINVAL instead of a device fault."""
