@@ -502,8 +502,12 @@ hipError_t launch_conv_h16(ConvArgs a, hipStream_t s) {
     // (measured and dropped: 32x16-pixel items with a 16-float chunk and a 3-unit ring for the Cin, Cout <= 32 layers -
     // 4 m-tiles per wave spill 104 bytes in the single-chunk variant, branch 0 went from 3.95 to 4.17 ms per step)
     // Cin <= 32 elements, Cout <= 32, one group: the layer's 18 weight fragments stay in registers (RING = -1)
+    // ... on EIGHT compute waves (two per SIMD, one m-tile each, 152 registers): these single-chunk items have nothing to
+    // overlap a wave's epilogue and fragment latencies with except the SIMD's other wave - 0.055 -> 0.049 ms per launch
+    // (conv_bench --cfg 904 = four waves).  The multi-chunk kernels lose with eight waves (64->64: 0.042 -> 0.048 ms).
     if (n32 && a.groups == 1 && a.cin8 <= 2 && !a.out_f32 && conv_forced_cfg() != 902)
-      return launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 16, 4, false, -1>(a, s);
+      return conv_forced_cfg() == 904 ? launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 16, 4, false, -1>(a, s)
+                                      : launch_h16<3, 1, 16, 16, 8, 1, 1, 1, 16, 4, false, -1>(a, s);
     return launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 32, 4, true>(a, s);
   }
   if (a.ks == 3 && a.stride == 2) {
