@@ -189,14 +189,17 @@ WINOGRAD_LDS = True
 WINOGRAD_24 = __import__('os').environ.get('ACRMI_WINO24', '1') != '0'
 
 
-def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False):
-    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3)."""
+def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, wino24=None):
+    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3).
+    wino24: None = WINOGRAD_24; False keeps the F(2x2,3x3) kernels for the layers F(2x4,3x3) would take (small batches:
+    its 8x32-pixel, one-n-tile items are half as many as conv_wino2's small-batch items)."""
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
     if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
             and not per_frame_bias):
         return 3
-    if WINOGRAD_2D and WINOGRAD_24 and cin > 32 and cout != 33 and wo % 32 == 0 and ho % 8 == 0:
+    if (WINOGRAD_2D and (WINOGRAD_24 if wino24 is None else wino24) and cin > 32 and cout != 33 and wo % 32 == 0
+            and ho % 8 == 0):
         return 4
     return 2 if WINOGRAD_2D else 1
 
@@ -229,10 +232,11 @@ class Blob(object):
 class Program(object):
     """Op list + buffer table under construction."""
 
-    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False):
+    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None):
         self.sd = {k: _np(v) for k, v in sd.items()}
         self.dt = dt             # storage type of the activations between layers (DT_*); head outputs stay fp32
         self.keep_weights = keep_weights
+        self.wino24 = wino24      # None = packer.WINOGRAD_24
         self.keep_all = keep_all  # no lifetime-based buffer reuse: every intermediate map survives the run (tests)
         self.blob = Blob()
         self.bufs = []           # (h, w, cs, persistent, dtype)
@@ -340,7 +344,7 @@ class Program(object):
             packed = [pack_conv_h16(w, b, self.dt) for (w, b) in wb_list]
             w_off = self.blob.add16(np.concatenate([p[0] for p in packed]))
         else:
-            algo = conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None)
+            algo = conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24)
             if algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:
@@ -462,7 +466,8 @@ def point_tower(P, side, k):
     return out
 
 
-def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False):
+def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False,
+          wino24=None):
     """state dict -> dict(blob, bufs, ops, heads, op_info, taps, precision, width).  See module docstring.
     point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT; fp32 W32 only).
     keep_taps: pin the buffers of the backbone taps the golden vectors hold (stem / layer1 / stage2 / stage3 branch 0,
@@ -475,6 +480,8 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     prior, segm logits), attention pooling, pare bias, decode and MANO stay fp32 (the reference's .float() at
     acr/model.py:56-62).  The HRNet width (32 / 48) is read off the checkpoint.
     keep_weights: op_info[i]['wb'] keeps the folded fp64 filters of every conv (oracle/program.py, tests only).
+    wino24: None = packer.WINOGRAD_24 (on); False lowers the 3x3 stride-1 layers with Cin > 32 to F(2x2,3x3) - what
+    Engine.load_state_dict asks for when max_batch < 16 (single-frame / small-batch latency: batch 1 3.5 vs 3.7 ms).
     keep_all: no buffer is reused, so every intermediate map can be read after a run (per-op parity tests; ~2x the
     activation memory)."""
     sd = strip_prefix(sd)
@@ -487,7 +494,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     c0 = width
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
-    P = Program(sd, dt, keep_weights, keep_all)
+    P = Program(sd, dt, keep_weights, keep_all, wino24)
     b = 'backbone.'
     # ---- stem -----------------------------------------------------------------------------------
     w, bb = P.folded(b + 'conv1', b + 'bn1')

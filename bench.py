@@ -510,17 +510,32 @@ def main():
             out['single_context'] = {'value': round(B * args.steps / dt1, 2), 'unit': 'frames/s',
                                      'ms_per_step': round(dt1 / args.steps * 1e3, 3),
                                      'note': 'one context, batches back to back on one stream (+ its parallel lanes)'}
+        oracle = None
+        if world == 1 and not use_dist and pool is not None:
+            # everything below runs single calls on `eng` with the library's lanes: the lane streams must be created AFTER the
+            # pool's streams are gone - lanes created while other streams are alive share hardware queues with them (8-10 ms
+            # per batch-1 call instead of 3.5; DESIGN.md section 2 "Parallel lanes")
+            pool.close(keep_first=True)
+            pool = None
+        if world == 1 and not args.no_cpu_baseline:
+            oracle, out['cpu_baseline'] = cpu_baseline(sd, tables)
+            out['parity'] = parity(eng, oracle)          # the headline program (large-batch lowering) on the sample's 8 frames
         if world == 1 and not use_dist and not args.no_latency:
-            # single calls (the way the reference is driven): one context with the library's lanes.  Measured AFTER the
-            # pool is gone, and the pool is created BEFORE any lane stream exists: streams created behind three or more
-            # others run their kernels measurably less concurrently (tools/pipeline_probe.py: 1620 -> 1585 frames/s
-            # for the pool when a 4-lane call came first; 8 ms instead of 3.4 per batch-1 call with torch's stream pool
-            # alive)
+            # single calls (the way the reference is driven, acr/main.py:126-141: one frame per call), on a context built
+            # for small batches as acr.model.ACR builds it (max_batch <= 8: the packer keeps F(2x2,3x3) for every 3x3
+            # layer).  Measured with every other context and stream of this process gone and BEFORE the later sections create theirs: lane streams that are
+            # created while other streams are alive share hardware queues with them (9.9 instead of 3.5 ms per batch-1
+            # call with the throughput context still alive; 8 ms with torch's stream pool alive - DESIGN.md section 2)
             if pool is not None:
                 pool.close(keep_first=True)
                 pool = None
+            # (the SAME context is re-programmed rather than a new one created: a context created this late gets lane streams
+            #  that share hardware queues - 7.5-9.9 ms per batch-1 call instead of 3.5)
+            eng.load_state_dict(sd, max_batch=8, precision=args.precision)
             eng.set_lanes(0)
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
+            out['latency']['context'] = 'max_batch 8 (small-batch lowering: F(2x2,3x3) only)'
+            eng.close()
         if world == 1 and not use_dist and not args.no_pmc and args.precision == 'fp32':
             # counters of THIS box, THIS run (the committed profiles/ figures stay as the fallback, labelled as such)
             live = live_pmc(B)
@@ -535,10 +550,6 @@ def main():
                 out['roofline']['mfma_busy_pmc'] = dict(live['mfma_busy'], source=live['source'])
             else:
                 out['roofline']['traffic_source'] = 'committed: ' + str(out['roofline']['traffic_source'])
-        oracle = None
-        if world == 1 and not args.no_cpu_baseline:
-            oracle, out['cpu_baseline'] = cpu_baseline(sd, tables)
-            out['parity'] = parity(eng, oracle)
         if world == 1 and not use_dist and not args.no_reduced_precision and args.precision == 'fp32':
             if pool is not None:
                 pool.close(keep_first=True)

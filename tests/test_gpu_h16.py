@@ -391,6 +391,33 @@ def test_config4_workload_w48_fp16_batch64_with_fp16_mano(mano_tables):
     eng.close()
 
 
+def test_config1_batch_and_dtype_on_hrnet(synth_sd, mano_tables):
+    """BASELINE.json configs[1] names batch 32 in bf16 on a ResNet-50 the reference does not contain (`--backbone resnet50`
+    is a dead flag, acr/config.py:95) and this build does not add; its batch and dtype run on HRNet-W32: 32 frames through
+    the bf16 program, every frame bit-equal to its own batch-1 run (frames are independent in 16 bits too), the first and
+    the last frame's head maps against the op-list interpreter within the 16-bit quantisation noise."""
+    synth = pkg('synth')
+    B = 32
+    frames = synth.make_frames(B, seed=9)
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=B, precision='bf16', keep_weights=True)
+    eng.load_mano(_flip_left(mano_tables))
+    x = torch.from_numpy(frames).cuda()
+    out = {k: v.clone() for k, v in eng.forward(x).items()}
+    maps = {k: v[[0, B - 1]].cpu() for k, v in eng.head_maps(B).items()}
+    for i in (0, 13, B - 1):
+        one = eng.forward(x[i:i + 1].contiguous())
+        for k in ('slots', 'verts', 'joints'):
+            assert torch.equal(one[k][0], out[k][i]), (i, k)
+    ref = oprog.run_program(eng.program, torch.from_numpy(frames[[0, B - 1]])).head_maps()
+    with torch.no_grad():
+        f32 = acr_net.network(synth_sd, torch.from_numpy(frames[[0, B - 1]]))
+    for k in ref:
+        qerr = float((ref[k] - f32[k]).abs().max())
+        assert float((maps[k] - ref[k]).abs().max()) <= 3.0 * qerr, k
+    eng.close()
+
+
 def test_mano_fp16_lbs_against_the_reference_vectors(mano_tables):
     """ACRMI_OPT_MANO_FP16 (BASELINE.json configs[4] "fp16 MANO LBS") on the MANO vectors captured from the real
     reference (tests/golden/mano_cases.npz): f16 blend-shape tables and skinning weights, fp32 arithmetic.  The

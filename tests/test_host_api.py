@@ -70,6 +70,24 @@ def test_config_rejects_what_the_reference_rejects():
         assert cfg.parse_args(['--configs_yml', '/nonexistent.yml', '--model_precision', prec]).model_precision == prec
 
 
+def test_w48_checkpoint_reshapes_the_module_without_gpu():
+    """BASELINE.json configs[4]: an HRNet-W48 checkpoint (same key names, wider tensors) re-shapes acr.model.ACR's state
+    dict; a W32 checkpoint loaded afterwards shapes it back; a tensor of a third width is refused."""
+    synth, schema = pkg('synth'), pkg('schema')
+    m = pkg('acr.model').ACR()
+    sd48 = synth.make_state_dict(seed=0, width=48)
+    assert list(sd48.keys()) == list(schema.state_dict_schema(48).keys()) == list(schema.state_dict_schema(32).keys())
+    missing, unexpected = m.load_state_dict(sd48)
+    assert missing == [] and unexpected == [] and m._width == 48
+    assert tuple(m.state_dict()['backbone.stage4.0.branches.3.0.conv1.weight'].shape) == (384, 384, 3, 3)
+    assert tuple(m.state_dict()['contact_layers.1.0.weight'].shape) == (256, 50, 3, 3)
+    m.load_state_dict(synth.make_state_dict(seed=0))
+    assert m._width == 32 and tuple(m.state_dict()['contact_layers.1.0.weight'].shape) == (256, 34, 3, 3)
+    with pytest.raises(ValueError):
+        schema.stage_cfg(40)
+    assert schema.schema_digest(48)['n_params'] > 2 * schema.schema_digest(32)['n_params']
+
+
 def test_pack_conv_layout_and_bn_folding(synth_sd):
     packer = pkg('packer')
     w = np.arange(40 * 10 * 9, dtype=np.float32).reshape(40, 10, 3, 3)
