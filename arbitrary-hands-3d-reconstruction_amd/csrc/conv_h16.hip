@@ -93,12 +93,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
   constexpr int BUF = PH * PW * CP;
   constexpr int SPC = CK / 8;                       // 16-element steps per full chunk
   constexpr bool WREG = RING < 0;                    // the layer's weights live in registers
-  constexpr int SU = TAPS == 1 ? 4 : (WREG ? 2 : 1); // steps per statically unrolled pass
+  constexpr int SU = TAPS == 1 ? 4 : (WREG ? CK / 8 : 1); // steps per statically unrolled pass (WREG: the whole chunk)
   constexpr int UNITS = SU * TAPS;                  // (step, tap) units per pass
   // weight-fragment ring (L2 latency; a unit is MT*NTW MFMAs of 32 cycles): 9 units deep where the registers allow it
   // (two n-tiles per wave: 72 registers of fragments next to 64 of accumulators and the residual prefetch spill)
-  constexpr int R = TAPS == 1 ? 4 : (WREG ? 2 * TAPS : (RING ? RING : (NTW >= 2 ? 3 : 9)));
-  static_assert(!WREG || (ONE && TAPS == 9 && NTW == 1 && WAVES_N == 1 && CK == 16), "register-resident weights: 3x3, one chunk of <= 2 steps, one n-tile");
+  constexpr int R = TAPS == 1 ? 4 : (WREG ? (CK / 8) * TAPS : (RING ? RING : (NTW >= 2 ? 3 : 9)));
+  static_assert(!WREG || (ONE && TAPS == 9 && NTW == 1 && WAVES_N == 1 && (CK == 16 || CK == 32)),
+                "register-resident weights: 3x3, one chunk of <= 4 steps, one n-tile per wave and item");
   // activation-fragment ring (LDS latency).  Measured: 6 / 9 deep instead of 3 changes nothing (the 195 cycles per
   // 64-cycle unit in the stamps are not LDS latency) and spills the 1x1 fp32-output kernels
   constexpr int RA = TAPS == 1 ? 2 : 3;
@@ -508,6 +509,8 @@ hipError_t launch_conv_h16(ConvArgs a, hipStream_t s) {
     if (n32 && a.groups == 1 && a.cin8 <= 2 && !a.out_f32 && conv_forced_cfg() != 902)
       return conv_forced_cfg() == 904 ? launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 16, 4, false, -1>(a, s)
                                       : launch_h16<3, 1, 16, 16, 8, 1, 1, 1, 16, 4, false, -1>(a, s);
+    // (measured and dropped: the same for Cin <= 64 elements - 36 fragments = 144 registers, a persistent workgroup sees
+    // the same n-tile in every item when grid % n_tiles == 0 - spills 76 bytes and is no faster: 64->64 0.042 ms either way)
     return launch_h16<3, 1, 16, 16, 4, 2, 1, 1, 32, 4, true>(a, s);
   }
   if (a.ks == 3 && a.stride == 2) {
