@@ -365,9 +365,12 @@ class EnginePool(object):
         except Exception:
             pass
 
-    def load_state_dict(self, sd, max_batch=1, lanes=1, precision='fp32'):
-        """sd = None: share the program context 0 already holds."""
-        prog = self.engines[0].program if sd is None else packer.lower(sd, precision=precision)
+    def load_state_dict(self, sd, max_batch=1, lanes=1, precision='fp32', wino24='auto'):
+        """sd = None: share the program context 0 already holds.  wino24 as Engine.load_state_dict (the same
+        checkpoint at the same max_batch lowers to the same program on an Engine and on a pool: bit-equal results)."""
+        if wino24 == 'auto':
+            wino24 = None if max_batch >= 16 else False
+        prog = self.engines[0].program if sd is None else packer.lower(sd, precision=precision, wino24=wino24)
         if prog is None:
             raise _lib.AcrmiError('no checkpoint loaded')
         for e in self.engines:
