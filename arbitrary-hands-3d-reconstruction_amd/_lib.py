@@ -8,7 +8,9 @@ LIB_PATH = os.environ.get('ACRMI_LIB') or os.path.join(HERE, 'libacrmi.so')   # 
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
+CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV / acrmi_conv2d's algo: ACRMI_CONV_BIAS_MAP
 OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF, OPT_MANO_FP16 = 1, 2, 3, 4, 5, 6, 7
+OPT_LANE_PLAN = 8
 VERSION = 300
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SLOT = 176

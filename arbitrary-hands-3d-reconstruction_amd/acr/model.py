@@ -93,6 +93,10 @@ class ACR(object):
                 eng.adopt(self._retired)
                 self._retired.close()
                 self._retired = None
+            else:
+                # the demo loop's operating point is one frame per call (acr/main.py:126-141): lanes by measurement in
+                # the host process's actual stream / hardware-queue state (Engine.tune_lanes)
+                eng.tune_lanes(1)
             self._engine = eng
         else:
             self._engine.ensure_batch(min_batch)

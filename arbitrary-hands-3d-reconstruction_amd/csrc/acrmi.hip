@@ -49,6 +49,10 @@ struct acrmi_ctx {
   Schedule sched[2][2];         // [point][0: small batches / 1: large batches]
   // ACRMI_OPT_LANES: independent chains of the program on parallel HIP streams (lane 0 = the caller's stream)
   int want_lanes = 0;           // 0 = by batch size (AUTO_LANES_*)
+  // ACRMI_OPT_LANE_PLAN: lane per op from MEASURED op times (acrmi_profile_ops at a small batch stores them here), small-
+  // batch schedules only; empty = the structural heuristic
+  bool lane_plan = true;
+  std::vector<float> op_ms[2];  // [point]: per-op milliseconds of the last small-batch profile
   hipStream_t lanes[MAX_LANES] = {};
   hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {};
   std::vector<hipEvent_t> op_ev;
@@ -213,6 +217,9 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       a.in_cs = di.cs; a.in_coff = op.in_coff; a.Cin = op.cin;
       a.out_cs = dout.cs; a.out_coff = op.out_coff; a.Cout = op.cout;
       a.res_cs = op.res_buf >= 0 ? desc(op.res_buf).cs : 0; a.res_coff = op.res_coff;
+      if (op.flags & ACRMI_CONV_BIAS_MAP) {   // position-bias map in the weight blob, added to every frame
+        a.res = c->weights + op.w_off2; a.res_cs = (op.groups * op.cout + 3) / 4 * 4; a.res_coff = 0; a.res_bcast = 1;
+      }
       a.ks = op.ksize; a.stride = op.stride; a.relu = op.relu; a.groups = op.groups;
       a.cin8 = (op.cin + 7) / 8;
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
@@ -350,21 +357,51 @@ static void build_schedule(acrmi_ctx* c, bool point, bool large) {
     for (int b : W) { last_writer[b] = j; readers[b].clear(); }
     for (int d : deps) S.leaf[d] = 0;
   }
-  // lanes: an op continues the lane of a producer that is still that lane's tail (the producer of in_buf first),
-  // otherwise it opens a lane, or takes the one whose tail is oldest
   const int want = c->want_lanes > 0 ? c->want_lanes : (large ? AUTO_LANES_LARGE : AUTO_LANES_SMALL);
   const int max_lanes = std::max(1, std::min(want, MAX_LANES));
   S.lane.assign(n, 0);
   S.wait.assign(n, std::vector<int>());
   S.signal.assign(n, 0);
   std::vector<int> lane_tail(max_lanes, -1);
+  const std::vector<float>& ms = c->op_ms[point ? 1 : 0];
+  const bool planned = c->lane_plan && !large && max_lanes > 1 && (int)ms.size() == n;
+  // Planned form (small batches, where a launch leaves most CUs idle and concurrent lanes really overlap): list
+  // scheduling with the measured op times - every op, in program order, goes to the lane where it can START first.
+  // Cost model measured on MI355X (tools/cross_stream_wait.py, tools/critical_path.py): a dependent kernel in the same
+  // stream starts ~4.5 us after its producer ends, through an event on another stream ~21 us after (WAIT_MS below is the
+  // difference); every other lane waited for costs the consumer's queue one barrier packet (SYNC_MS).
+  constexpr float SYNC_MS = 0.002f, EVENT_MS = 0.002f;   // (EVENT_MS: what a profiled time includes)
+  static const float WAIT_MS = getenv("ACRMI_PLAN_WAIT_US") ? 1e-3f * (float)atof(getenv("ACRMI_PLAN_WAIT_US")) : 0.016f;
+  std::vector<float> fin(planned ? n : 0, 0.f), lane_free(max_lanes, 0.f);
   for (int j : S.order) {
     int lane = -1;
-    for (int d : S.deps[j])
-      if (lane_tail[S.lane[d]] == d) { lane = S.lane[d]; break; }
-    if (lane < 0) {
-      if (S.n_lanes < max_lanes) lane = S.n_lanes++;
-      else lane = (int)(std::min_element(lane_tail.begin(), lane_tail.end()) - lane_tail.begin());
+    if (planned) {
+      float best = 0.f;
+      bool best_prod = false;
+      for (int l = 0; l < max_lanes; ++l) {
+        float start = lane_free[l];
+        unsigned others = 0;
+        bool prod = false;
+        for (int d : S.deps[j]) {
+          if (S.lane[d] == l) { prod = true; continue; }
+          others |= 1u << S.lane[d];
+          start = std::max(start, fin[d] + WAIT_MS);
+        }
+        start += SYNC_MS * (float)__builtin_popcount(others);
+        if (lane < 0 || start < best - 1e-6f || (start < best + 1e-6f && prod && !best_prod)) { lane = l; best = start; best_prod = prod; }
+      }
+      fin[j] = best + std::max(ms[j] - EVENT_MS, 0.002f);
+      lane_free[lane] = fin[j] + 0.5f * SYNC_MS;
+      S.n_lanes = std::max(S.n_lanes, lane + 1);
+    } else {
+      // structural heuristic: an op continues the lane of a producer that is still that lane's tail (the producer of
+      // in_buf first), otherwise it opens a lane, or takes the one whose tail is oldest
+      for (int d : S.deps[j])
+        if (lane_tail[S.lane[d]] == d) { lane = S.lane[d]; break; }
+      if (lane < 0) {
+        if (S.n_lanes < max_lanes) lane = S.n_lanes++;
+        else lane = (int)(std::min_element(lane_tail.begin(), lane_tail.end()) - lane_tail.begin());
+      }
     }
     S.lane[j] = lane;
     std::vector<int> latest(max_lanes, -1);      // waiting for a lane's latest op covers its earlier ones
@@ -385,8 +422,9 @@ static void build_schedule(acrmi_ctx* c, bool point, bool large) {
     }
     int waits = 0;
     for (int j : S.order) waits += (int)S.wait[j].size();
-    fprintf(stderr, "[acrmi] schedule(%s, %s batches): %zu ops, %d edges, critical path %d ops; %d lanes, %d cross-lane waits\n",
-            point ? "point" : "dense", large ? "large" : "small", S.order.size(), edges, maxd, S.n_lanes, waits);
+    fprintf(stderr, "[acrmi] schedule(%s, %s batches, %s): %zu ops, %d edges, critical path %d ops; %d lanes, %d cross-lane waits\n",
+            point ? "point" : "dense", large ? "large" : "small", planned ? "planned from measured op times" : "structural",
+            S.order.size(), edges, maxd, S.n_lanes, waits);
   }
 }
 
@@ -456,6 +494,12 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         return fail(c, ACRMI_EINVAL, "op %d: conv buffer types do not fit (in %d, out %d, algo %d)", i, idt, odt, algo);
       if (op.res_buf >= 0 && bufs[op.res_buf].dtype != odt)
         return fail(c, ACRMI_EINVAL, "op %d: the residual must have the type of the output", i);
+      if (op.flags & ACRMI_CONV_BIAS_MAP) {
+        const long long mcs = (op.groups * op.cout + 3) / 4 * 4;
+        if (op.res_buf >= 0 || idt || algo == 3 || !w_ok(op.w_off2, (long long)bufs[op.out_buf].h * bufs[op.out_buf].w * mcs))
+          return fail(c, ACRMI_EINVAL, "op %d: a position-bias map needs an fp32 conv without a residual buffer (not algo 3) and "
+                      "[Ho][Wo][round4(groups*Cout)] floats inside the blob at w_off2", i);
+      }
       if (op.bias_per_frame && buf_ok(op.aux_buf) && bufs[op.aux_buf].dtype != ACRMI_DT_F32)
         return fail(c, ACRMI_EINVAL, "op %d: the per-frame bias must be fp32", i);
       if (algo != 0 && !(op.ksize == 3 && op.stride == 1))
@@ -557,6 +601,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
   HIPCHK(c, hipMalloc(&c->picks, (size_t)max_batch * 4 * sizeof(int)));
+  c->op_ms[0].clear(); c->op_ms[1].clear();      // measured times belong to the previous program
   for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
   c->op_ev.assign(n_ops, nullptr);
   c->have_program = true;
@@ -628,24 +673,33 @@ int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float
 
 // The program with its independent chains on parallel streams: lane 0 is the caller's stream, the other lanes fork
 // from it (so they start after everything queued before this call) and join it at the end.
+static unsigned lane_event_flags() {
+  static const unsigned f = [] {
+    const char* e = getenv("ACRMI_EVENT_FLAGS");      // experiment switch: extra hipEventCreateWithFlags bits (hex)
+    return hipEventDisableTiming | (e ? (unsigned)strtoul(e, nullptr, 16) : 0u);
+  }();
+  return f;
+}
+
 static int run_program_lanes(acrmi_ctx* c, const uint8_t* img, int B, hipStream_t user, bool point) {
   const Schedule& S = c->sched[point ? 1 : 0][B > AUTO_SMALL_BATCH ? 1 : 0];
   for (int l = 1; l < S.n_lanes; ++l) {
     if (!c->lanes[l]) HIPCHK(c, hipStreamCreateWithFlags(&c->lanes[l], hipStreamNonBlocking));
-    if (!c->join_ev[l]) HIPCHK(c, hipEventCreateWithFlags(&c->join_ev[l], hipEventDisableTiming));
+    if (!c->join_ev[l]) HIPCHK(c, hipEventCreateWithFlags(&c->join_ev[l], lane_event_flags()));
   }
-  if (!c->fork_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+  if (!c->fork_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, lane_event_flags()));
   auto st = [&](int l) { return l == 0 ? user : c->lanes[l]; };
   HIPCHK(c, hipEventRecord(c->fork_ev, user));
   for (int l = 1; l < S.n_lanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->lanes[l], c->fork_ev, 0));
   int r = ACRMI_OK;
   for (int j : S.order) {
     hipStream_t s = st(S.lane[j]);
-    for (int d : S.wait[j]) HIPCHK(c, hipStreamWaitEvent(s, c->op_ev[d], 0));
+    static const int ablate = getenv("ACRMI_ABLATE_LANE_SYNC") ? atoi(getenv("ACRMI_ABLATE_LANE_SYNC")) : 0;   // timing ablation (WRONG results): 1 = no waits, 2 = no waits and no records
+    if (!(ablate & 1)) for (int d : S.wait[j]) HIPCHK(c, hipStreamWaitEvent(s, c->op_ev[d], 0));
     r = run_op(c, c->ops[j], img, B, s);
     if (r) break;
-    if (S.signal[j]) {
-      if (!c->op_ev[j]) HIPCHK(c, hipEventCreateWithFlags(&c->op_ev[j], hipEventDisableTiming));
+    if (S.signal[j] && !(ablate & 2)) {
+      if (!c->op_ev[j]) HIPCHK(c, hipEventCreateWithFlags(&c->op_ev[j], lane_event_flags()));
       HIPCHK(c, hipEventRecord(c->op_ev[j], s));
     }
   }
@@ -710,6 +764,12 @@ int acrmi_set_option(acrmi_ctx* c, int option, int value) {
   if (option == ACRMI_OPT_LANES) {
     if (value < 0 || value > MAX_LANES) return fail(c, ACRMI_EINVAL, "acrmi_set_option: lanes %d outside 0..%d", value, MAX_LANES);
     c->want_lanes = value;
+    if (c->have_program)
+      for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
+    return ACRMI_OK;
+  }
+  if (option == ACRMI_OPT_LANE_PLAN) {
+    c->lane_plan = value != 0;
     if (c->have_program)
       for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
     return ACRMI_OK;
@@ -805,6 +865,10 @@ int acrmi_profile_ops(acrmi_ctx* c, const uint8_t* img, int B, float* ms_out, in
   cleanup();
   if (r) return r;
   if (he != hipSuccess) return fail(c, ACRMI_EHIP, "acrmi_profile_ops: %s", hipGetErrorString(he));
+  if (B <= AUTO_SMALL_BATCH) {      // the small-batch schedules are planned from these times (ACRMI_OPT_LANE_PLAN)
+    c->op_ms[point ? 1 : 0].assign(ms_out, ms_out + n);
+    build_schedule(c, point, false);
+  }
   return n;
 }
 
@@ -913,6 +977,10 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                  void* stream) {
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0)
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: bad arguments");
+  const int bias_map = algo >= 0 ? (algo & ACRMI_CONV_BIAS_MAP) : 0;      // res = ONE map [Ho][Wo][res_cs] for all frames
+  if (algo >= 0) algo &= ~ACRMI_CONV_BIAS_MAP;
+  if (bias_map && (!res || algo == 3))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: ACRMI_CONV_BIAS_MAP needs res (the map) and an algo other than 3");
   if (algo != 0 && !((algo >= 1 && algo <= 4) && ksize == 3 && stride == 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-1 convolution", algo);
   if (algo == 3 && (groups != 1 || cin > 32 || cout != 32 || bias_frame_stride != 0 || H % 8 || W % 16 || out_cs % 4 ||
@@ -940,6 +1008,7 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   a.n_tiles = cout <= 32 ? 1 : ((cout + 63) / 64) * 2;
   a.bias_fstride = bias_frame_stride;
   a.algo = algo;
+  a.res_bcast = bias_map ? 1 : 0;
   hipError_t e = launch_conv(a, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
   return ACRMI_OK;

@@ -69,6 +69,16 @@ __device__ __forceinline__ ItemPos item_pos(const ConvWork& wk, int w) {
   return p;
 }
 
+// Residual addressing: a frame's residual map starts res_frame_off floats (elements) behind a.res; a BROADCAST residual
+// (a.res_bcast: one [Ho][Wo][res_cs] map added to every frame - the position-bias map that stands for the coordinate
+// channels of the head convs, packer.coord_bias_map) has a single frame.
+__device__ __forceinline__ size_t res_frame_off(const ConvArgs& a, int b) {
+  return a.res_bcast ? (size_t)0 : (size_t)b * a.Ho * a.Wo * a.res_cs;
+}
+__device__ __forceinline__ size_t res_total(const ConvArgs& a) {
+  return (size_t)(a.res_bcast ? 1 : a.B) * a.Ho * a.Wo * a.res_cs;
+}
+
 // Bytes of bias behind group g's origin inside one bias row.  The epilogues read whole 32-channel n-tiles through a
 // buffer descriptor; a per-frame bias row is only bias_fstride floats long (< n_tiles*32 for a ragged Cout), so the
 // descriptor ends at the row: the tail channels read 0 (they are masked at the store) instead of running past the

@@ -208,7 +208,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
       item_rest = ip.rest;
       bias = a.bias + (size_t)g * a.n_tiles * 32 + (size_t)b * a.bias_fstride;
       outb = out_c + ((size_t)b * a.Ho * a.Wo * a.out_cs + a.out_coff + g * a.Cout) * ESZ;
-      resb = has_res ? res_c + ((size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout) * ESZ : nullptr;
+      resb = has_res ? res_c + (res_frame_off(a, b) + a.res_coff + g * a.Cout) * ESZ : nullptr;
       vec_align = ((a.out_coff + g * a.Cout) % CPL == 0) && (a.out_cs % CPL == 0) &&
                   (!has_res || (((a.res_coff + g * a.Cout) % CPL == 0) && (a.res_cs % CPL == 0)));
       const bool full_tile = (ty0 + TH <= a.Ho) && (tx0 + TW <= a.Wo);
@@ -223,8 +223,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, 1) void conv_h16_ke
           x = x < a.Wo ? x : a.Wo - 1;
           pix[m][gq] = y * a.Wo + x;
         }
-      const size_t res_off = (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout;
-      const size_t res_left = ((size_t)a.B * a.Ho * a.Wo * a.res_cs - res_off) * ESZ;
+      const size_t res_off = res_frame_off(a, b) + a.res_coff + g * a.Cout;
+      const size_t res_left = (res_total(a) - res_off) * ESZ;
       rrsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(has_res ? resb : reinterpret_cast<const char*>(a.in)), 0,
           (has_res && vec_align) ? (int)(unsigned)(res_left > 0xffffffffu ? 0xffffffffu : res_left) : 0, 0x00020000);

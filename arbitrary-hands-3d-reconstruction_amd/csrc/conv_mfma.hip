@@ -257,7 +257,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_win
       const int b = tile / wk.tiles_per_frame;
       const int t = tile - b * wk.tiles_per_frame;
       const int ty0 = (t / wk.tiles_x) * TH, tx0 = (t % wk.tiles_x) * TW;
-      const float* __restrict__ resb = a.res + (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout;
+      const float* __restrict__ resb = a.res + res_frame_off(a, b) + a.res_coff + g * a.Cout;
       float* dst = res_base + (seq & 1) * RES;
       f32x4 rv[NIT];
 #pragma unroll
@@ -377,7 +377,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + NLW) * 64, MINW) void conv_win
       EpiCtx e;
       e.bias = a.bias + (size_t)g * a.n_tiles * 32 + (size_t)b * a.bias_fstride;
       e.outb = a.out + (size_t)b * a.Ho * a.Wo * a.out_cs + a.out_coff + g * a.Cout;
-      e.resb = has_res ? a.res + (size_t)b * a.Ho * a.Wo * a.res_cs + a.res_coff + g * a.Cout : nullptr;
+      e.resb = has_res ? a.res + res_frame_off(a, b) + a.res_coff + g * a.Cout : nullptr;
       e.res_cs = a.res_cs; e.out_cs = a.out_cs; e.Cout = a.Cout; e.relu = a.relu;
       e.vec_align = ((a.out_coff + g * a.Cout) % 4 == 0) && (a.out_cs % 4 == 0) &&
                     (!has_res || (((a.res_coff + g * a.Cout) % 4 == 0) && (a.res_cs % 4 == 0)));

@@ -32,6 +32,7 @@ struct ConvArgs {
   // packer.pack_conv_h16 fragments and algo must be 0 (conv_h16.hip).
   int dtype;
   int out_f32;          // 16-bit input, fp32 output and fp32 residual (the head exits)
+  int res_bcast;        // 1: res is ONE [Ho][Wo][res_cs] map added to every frame (not conv_wino3 / the 16-bit kernels)
 };
 
 // one-time per-DEVICE kernel setup (dynamic LDS attribute): true the first time `flags` (one static array per kernel

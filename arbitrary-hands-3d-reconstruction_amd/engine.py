@@ -29,6 +29,7 @@ class Engine(object):
         self.have_mano = False
         self.point_heads = False
         self.lanes = 0
+        self.lane_plan = True
         self.conf_thresh = 0.35
         self.center_idx = 9
         self.temporal = False
@@ -94,6 +95,49 @@ class Engine(object):
         0 = by batch size: the library default)."""
         _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_LANES, int(n)), self.ctx)
         self.lanes = int(n)
+
+    def set_lane_plan(self, on):
+        """ACRMI_OPT_LANE_PLAN: small-batch schedules assign lanes from the op times the last `profile_ops` measured
+        (list scheduling) instead of from the structure of the graph alone."""
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_LANE_PLAN, int(bool(on))), self.ctx)
+        self.lane_plan = bool(on)
+
+    def tune_lanes(self, batch=1, candidates=(1, 2, 4, 6), calls=5):
+        """Picks ACRMI_OPT_LANES / ACRMI_OPT_LANE_PLAN by measurement IN THIS PROCESS: the ops are profiled once (the
+        library keeps the times and plans the lanes from them), then every candidate lane count is timed with the
+        structural and with the planned assignment - `calls` network passes (acrmi_backbone_heads on zero frames,
+        after 2 warm-ups) each - and the fastest is set.  Why: what parallel lanes gain depends on state the library
+        cannot see - ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; the package only
+        sets 8 when it is imported before HIP starts), and lane streams created next to other live streams (torch's
+        pools, RCCL, another context) may share a queue with them: measured 7.5-9.9 ms per batch-1 call with four lanes
+        in that state against 3.4 ms with their own queues and 5.0 ms on one stream.  Results do not depend on the
+        assignment (same kernels, same order per buffer).  When the winner is what the library picks by itself for this
+        batch (4 lanes below 32 frames, 2 from 32 on) the lane option goes back to 0 = by batch size, so other batch
+        sizes keep their own default.  Returns ((lanes, planned), {(lanes, planned): ms})."""
+        import time
+        if self.program is None:
+            raise _lib.AcrmiError('no checkpoint loaded')
+        x = torch.zeros(batch, 512, 512, 3, dtype=torch.uint8, device=self.device)
+        self.set_lanes(1)
+        self.profile_ops(x)
+        self.profile_ops(x)           # (warm) these times are what the planned schedules use
+        ms = {}
+        for n in candidates:
+            for planned in ((False,) if n == 1 else (False, True)):
+                self.set_lane_plan(planned)
+                self.set_lanes(n)
+                for _ in range(2):
+                    self.backbone_heads(x)
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    self.backbone_heads(x)
+                torch.cuda.synchronize(self.device)
+                ms[(int(n), planned)] = (time.perf_counter() - t0) / calls * 1e3
+        best = min(ms, key=ms.get)
+        self.set_lane_plan(best[1])
+        self.set_lanes(0 if best[0] == (4 if batch < 32 else 2) else best[0])
+        return best, ms
 
     def set_conf_thresh(self, thresh):
         """ACRMI_OPT_CONF_THRESH = args().centermap_conf_thresh (acr/result_parser.py:198-205,241; strict >)."""

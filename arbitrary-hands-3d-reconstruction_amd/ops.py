@@ -36,7 +36,9 @@ def to_nhwc(x_nchw, cs=None, device='cuda'):
 def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, cin=None, in_coff=0, out=None,
            out_coff=0, out_cs=None, frame_bias=None, algo='direct'):
     """x: NHWC [B,H,W,cs] device fp32; weight: [Cout_total, Cin/groups, k, k] (torch/numpy, host or device);
-    padding = k//2 (the only padding the ACR network uses).  Returns NHWC [B,Ho,Wo,out_cs]."""
+    padding = k//2 (the only padding the ACR network uses).  Returns NHWC [B,Ho,Wo,out_cs].
+    residual: [B,Ho,Wo,rcs] added before the ReLU, or [1,Ho,Wo,rcs] = one map added to EVERY frame
+    (ACRMI_CONV_BIAS_MAP: the position-bias map of the head convs; not with 'winograd2d_lds')."""
     _need_cuda(x, residual, out, frame_bias)
     w = weight.detach().cpu().numpy() if hasattr(weight, 'detach') else np.asarray(weight)
     cout_t, cin_g, k, _ = w.shape
@@ -71,6 +73,8 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     bias_t, fstride = bp, 0
     if frame_bias is not None:
         bias_t, fstride = frame_bias.contiguous(), frame_bias.shape[-1]
+    if residual is not None and residual.shape[0] == 1 and B > 1:
+        algo_id |= _lib.CONV_BIAS_MAP
     L = _lib.lib()
     _lib.check(L.acrmi_conv2d(_p(x), B, H, W, cs, in_coff, cin, _p(wp), _p(bias_t), fstride, _p(residual),
                               residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1], out_coff,

@@ -204,6 +204,38 @@ def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, 
     return 2 if WINOGRAD_2D else 1
 
 
+# The head convs that read the 32 + 2 channel map (backbone output + coordinate maps, acr/model.py:52): the coordinate
+# channels are the same for every frame, so their share of the contraction is a per-pixel bias - conv(coord maps, their
+# filter columns), zero padding included - computed here once and added by the kernels like a residual shared by all
+# frames (ACRMI_CONV_BIAS_MAP).  Cin 34 -> 32: one 32-channel chunk instead of two for the Winograd kernels, two
+# 16-channel chunks instead of three for the stride-2 one.  fp32 programs only (a 16-bit map would be one more rounding).
+COORD_BIAS_MAP = True
+
+
+def coord_bias_map(wc, size, stride):
+    """wc [Cout,2,3,3] (fp64, BN-folded filter columns of the x and y coordinate channels) -> [Ho,Wo,round4(Cout)] fp64:
+    the 3x3 / padding-1 convolution of the size x size coordinate maps (the fp32 values coordfill_kernel writes,
+    acr/model.py:340-369) with wc."""
+    f32 = np.float32
+    t = ((np.arange(size, dtype=f32) / f32(size - 1)) * f32(2.0) - f32(1.0)).astype(np.float64)
+    cm = np.zeros((2, size + 2, size + 2))
+    cm[0, 1:-1, 1:-1] = t[None, :]
+    cm[1, 1:-1, 1:-1] = t[:, None]
+    ho = (size - 1) // stride + 1
+    cout = wc.shape[0]
+    out = np.zeros((ho, ho, (cout + 3) // 4 * 4))
+    for ky in range(3):
+        for kx in range(3):
+            patch = cm[:, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (ho - 1) + 1:stride]
+            out[:, :, :cout] += np.einsum('chw,oc->hwo', patch, wc[:, :, ky, kx])
+    return out
+
+
+# layer1.0's projection shortcut as extra input channels of its last 1x1 conv (Program.bottleneck): batch 64, fp32:
+# downsample 0.46 ms + conv3 0.51 ms -> one 128 -> 256 conv.
+FUSE_PROJECTION = True
+
+
 class Blob(object):
     def __init__(self):
         self.parts = [np.zeros(64, np.float32)]   # offset 0 reserved
@@ -315,8 +347,9 @@ class Program(object):
         return op
 
     def conv(self, name, src, wb_list, k, stride, relu, out=None, out_c=None, in_coff=0, out_coff=0, res=None,
-             res_coff=0, cin=None, bias_buf=None):
-        """wb_list: [(w, b)] one entry per group (all same shape)."""
+             res_coff=0, cin=None, bias_buf=None, bias_map=None):
+        """wb_list: [(w, b)] one entry per group (all same shape).  bias_map: [Ho,Wo,round4(groups*Cout)] added to every
+        frame before the ReLU (ACRMI_CONV_BIAS_MAP; fp32 programs, no residual)."""
         h, w_, _ = self.dims(src)
         cout, cin_w = wb_list[0][0].shape[:2]
         cin = cin_w if cin is None else cin
@@ -357,6 +390,11 @@ class Program(object):
                  in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
                  relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=algo,
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
+        if bias_map is not None:
+            assert res is None and self.dt == DT_F32 and algo != 3
+            assert bias_map.shape == (ho, wo, (cout * len(wb_list) + 3) // 4 * 4), bias_map.shape
+            self.ops[-1].flags = algo | _lib.CONV_BIAS_MAP
+            self.ops[-1].w_off2 = self.blob.add(bias_map)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
                                     'winograd_f2x4_3x3')[algo]
         if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
@@ -386,9 +424,24 @@ class Program(object):
         self.release(t, x)
         return y
 
-    def bottleneck(self, x, p):
-        """acr/model.py:519-539"""
-        t1 = self.conv_bn(x, p + '.conv1', p + '.bn1', 1, 1, True)
+    def bottleneck(self, x, p, cat=None):
+        """acr/model.py:519-539.  cat: x is channels [0, Cin) of the 2 Cin-channel buffer `cat` (a block with a projection
+        shortcut): the 3x3 conv writes its output next to x and the block's last conv + projection become ONE 1x1
+        convolution over the concatenated channels, y = relu([W_ds | W_3] [x ; t2] + b_ds + b_3) - the projected
+        shortcut (Cout channels written, then read back as a residual: 2 x 1.07 GB at batch 64 for layer1.0) never
+        exists."""
+        cin = self.sd[p + '.conv1.weight'].shape[1]
+        t1 = self.conv_bn(x, p + '.conv1', p + '.bn1', 1, 1, True, cin=cin)
+        if cat is not None:
+            assert cat == x and (p + '.downsample.0.weight') in self.sd
+            mid = self.sd[p + '.conv2.weight'].shape[0]
+            assert mid == cin and self.dims(cat)[2] >= 2 * cin
+            self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, 1, True, out=cat, out_coff=cin)
+            self.release(t1)
+            (wd, bd), (w3, b3) = self.folded(p + '.downsample.0', p + '.downsample.1'), self.folded(p + '.conv3', p + '.bn3')
+            y = self.conv(p + '.conv3+downsample', cat, [(np.concatenate([wd, w3], 1), bd + b3)], 1, 1, True)
+            self.release(cat)
+            return y
         t2 = self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, 1, True)
         self.release(t1)
         if (p + '.downsample.0.weight') in self.sd:
@@ -512,14 +565,17 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
         x = P.conv(b + 'conv1', x0, [(w, bb)], 3, 2, True, cin=3)
         P.op_info[-1]['flops'] = 2.0 * 256 * 256 * 64 * 3 * 9
         P.release(x0)
-    x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True)
+    # the stem's second conv writes channels 0..63 of a 128-channel map: layer1.0 puts its 3x3 output next to them and
+    # takes conv3 and the projection shortcut as one 128 -> 256 convolution (Program.bottleneck)
+    cat = P.buf(128, 128, 128) if FUSE_PROJECTION else None
+    x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True, out=cat)
     P.release(x)
     x = x1
     taps = {}
     if keep_taps:
         taps['stem'] = P.pin(x)
     for i in range(4):
-        x = P.bottleneck(x, b + 'layer1.%d' % i)
+        x = P.bottleneck(x, b + 'layer1.%d' % i, cat=cat if i == 0 else None)
     if keep_taps:
         taps['layer1'] = P.pin(x)
     # ---- stages ---------------------------------------------------------------------------------
@@ -562,12 +618,23 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     w_list = [P.folded('%s_final_layers.%d.0.0' % t, '%s_final_layers.%d.0.1' % t) for t in towers]
     wcat = np.concatenate([w for w, _ in w_list], 0)
     bcat = np.concatenate([bb for _, bb in w_list], 0)
+    coord_map = COORD_BIAS_MAP and dt == DT_F32
+
+    def head_conv(name, wb, stride, **kw):
+        """3x3 conv over the c0 + 2 channel map; fp32 programs: over its c0 backbone channels + the position-bias map"""
+        w, bb = wb
+        if not coord_map:
+            return P.conv(name, x34, [(w, bb)], 3, stride, True, cin=c0 + 2, **kw)
+        out = P.conv(name, x34, [(w[:, :c0], bb)], 3, stride, True, cin=c0, bias_map=coord_bias_map(w[:, c0:], 128, stride), **kw)
+        P.op_info[-1]['flops'] *= (c0 + 2.0) / c0          # the algorithmic figure keeps the coordinate channels
+        return out
+
     n0 = len(P.ops)
-    t0 = P.conv('towers.entry', x34, [(wcat, bcat)], 3, 2, True, cin=c0 + 2)
+    t0 = head_conv('towers.entry', (wcat, bcat), 2)
     P.set_mode(_lib.MODE_DENSE, n0)
     if point_heads:
         n0 = len(P.ops)
-        P.conv('towers.entry.centers', x34, [(wcat[:128], bcat[:128])], 3, 2, True, cin=c0 + 2, out=t0)
+        head_conv('towers.entry.centers', (wcat[:128], bcat[:128]), 2, out=t0)
         P.set_mode(_lib.MODE_POINT, n0)
     for k in range(2):
         c1 = [P.folded('%s_final_layers.%d.1.%d.0.conv1' % (s_, t_, k), '%s_final_layers.%d.1.%d.0.bn1' % (s_, t_, k))
@@ -636,7 +703,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     # folded into the Linear that consumes it (cam_shape_layers.2/3) below; the 256->64 conv over the 128x128 map and
     # 64 of the 320 pooled channels disappear.
     feat = P.buf(128, 128, 256)
-    P.conv('contact_layers.1.0', x34, [P.folded('contact_layers.1.0', 'contact_layers.1.1')], 3, 1, True, out=feat, cin=c0 + 2)
+    head_conv('contact_layers.1.0', P.folded('contact_layers.1.0', 'contact_layers.1.1'), 1, out=feat)
     pooled = P.buf(1, 32, 256, f32=True)
     P._op('attpool', 2.0 * 32 * 16384 * 320 + 2.0 * 128 * 128 * 256 * 64, kind=_lib.OP_ATTPOOL, in_buf=segm, res_buf=feat,
           out_buf=pooled, cin=256)

@@ -279,6 +279,9 @@ def latency(eng, frames, views_for, batches=(1, 8), iters=20):
     for b in batches:
         x = frames[:b].contiguous()
         v = views_for(b)
+        # lane count / assignment by measurement in this process (Engine.tune_lanes; what acr.model.ACR does at load time)
+        (lanes, planned), _ = eng.tune_lanes(b, candidates=(1, 2, 3, 4))
+        out['batch%d_lanes' % b] = '%d %s' % (lanes, 'planned from measured op times' if planned else 'structural')
         for _ in range(3):
             eng.forward(x, out=v)
         torch.cuda.synchronize()
@@ -535,6 +538,8 @@ def main():
             eng.set_lanes(0)
             out['latency'] = latency(eng, frames, lambda b: parallel.alloc_result(b, eng.device)[1])
             out['latency']['context'] = 'max_batch 8 (small-batch lowering: F(2x2,3x3) only)'
+            out['latency']['program_ops_per_call'] = sum(1 for o in eng.program['ops'] if o.mode != 2 and o.kind != 8)
+            out['latency']['launches_note'] = 'one launch per op except attention pooling (3); + decode (1) + MANO (1 per side)'
             eng.close()
         if world == 1 and not use_dist and not args.no_pmc and args.precision == 'fp32':
             # counters of THIS box, THIS run (the committed profiles/ figures stay as the fallback, labelled as such)

@@ -72,6 +72,13 @@ enum {
                              w_off = packer.pack_stem fragments [14][2][64], b_off = 64 biases */
 };
 
+/* acrmi_op.flags of a CONV, bit 3: a position-bias map - [Ho][Wo][round4(groups*Cout)] fp32 at blob offset w_off2 -
+ * is added to EVERY frame's output before the ReLU, in the place of a residual (res_buf must be -1; fp32 programs; not
+ * algo 3).  It stands for input channels that are a fixed function of the pixel position: the two coordinate channels
+ * of the reference's head convs (acr/model.py:52,340-369) leave the contraction (34 -> 32 input channels) and come back
+ * as conv(coord maps, their filter columns), computed once at lowering time (packer.coord_bias_map). */
+#define ACRMI_CONV_BIAS_MAP 8
+
 /* acrmi_op.mode: which variant of the head program an op belongs to. */
 enum {
   ACRMI_MODE_BOTH = 0,
@@ -91,8 +98,8 @@ typedef struct {
   int32_t nterms;                         /* FUSESUM */
   int32_t term_buf[4], term_coff[4], term_shift[4];
   int64_t w_off2, b_off2, w_off3;         /* PAREBIAS: linear weights/bias, mix-conv pare columns */
-  int32_t flags;                          /* CONV: algo (bits 0-2); PAREBIAS: part slice start (0 right /
-                                             16 left); POINTHEADS: side (0 left / 1 right)   */
+  int32_t flags;                          /* CONV: algo (bits 0-2) | ACRMI_CONV_BIAS_MAP; PAREBIAS: part slice start
+                                             (0 right / 16 left); POINTHEADS: side (0 left / 1 right) */
   int32_t mode;                           /* ACRMI_MODE_*                                    */
 } acrmi_op;
 
@@ -194,7 +201,8 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
  * 3 = Winograd F(2x2,3x3) with the layer's taps resident in LDS (groups 1, Cin <= 32, Cout = 32, H % 8 == 0,
  *     W % 16 == 0; w_packed = pack_wino3(w), 64 KiB);
  * 4 = Winograd F(2x4,3x3): F(2,3) along y, F(4,3) along x (3x3 stride 1, Cin > 32; w_packed =
- *     pack_conv(winograd24_weights(w)), 4x6 taps). */
+ *     pack_conv(winograd24_weights(w)), 4x6 taps).
+ * algo | ACRMI_CONV_BIAS_MAP (not with 3): res is ONE map [Ho][Wo][res_cs] added to every frame (see acrmi_op.flags). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
                  float* out, int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups,
@@ -261,6 +269,11 @@ int acrmi_parebias(const float* pooled_dev, int C, int part0, const float* lc_w_
  * acrmi_load_mano - half the table traffic per hand; all products and sums stay fp32, v_template / J_regressor / the
  * kinematic chain are untouched.  Measured deviation from the fp32 tables: see tests/test_gpu_h16.py. */
 #define ACRMI_OPT_MANO_FP16 7
+/* ACRMI_OPT_LANE_PLAN (0/1, default 1): once acrmi_profile_ops has run at a small batch (<= 32 frames), the lanes of the
+ * small-batch schedules are assigned by list scheduling over the MEASURED per-op times (every op goes to the lane where
+ * it can start first; a cross-stream dependency is charged what it costs on MI355X, ~16 us over an in-stream one)
+ * instead of by the structure of the graph alone.  Results do not depend on the assignment.  0 = structural only. */
+#define ACRMI_OPT_LANE_PLAN 8
 int acrmi_set_option(acrmi_ctx* ctx, int option, int value);
 /* ACRMI_OPT_CONF_THRESH (default 0.35): center score threshold, strict > (args().centermap_conf_thresh,
  * acr/result_parser.py:198-205,241).  ACRMI_OPT_SMOOTH_COEFF (default 4.0): One-Euro mincutoff of the pose filters

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
 MODE_POINT = 2
+CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV (include/acrmi.h)
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 
@@ -65,6 +66,9 @@ class Interp(object):
             y = y + torch.cat(bs)[None, None, None, :]
         y = y.to(torch.float32)                        # the kernels add bias / residual in fp32
         n = op.groups * op.cout
+        if op.flags & CONV_BIAS_MAP:                   # position-bias map in the blob: one map for every frame
+            ho, wo, cs = y.shape[1], y.shape[2], (n + 3) // 4 * 4
+            y = y + self.blob[op.w_off2:op.w_off2 + ho * wo * cs].view(1, ho, wo, cs)[..., :n]
         if op.res_buf >= 0:
             y = y + self.bufs[op.res_buf][..., op.res_coff:op.res_coff + n]
         if op.relu:

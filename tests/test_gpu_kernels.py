@@ -269,6 +269,45 @@ def test_conv3x3_channel_slices_frame_bias_residual(ops, algo):
         assert (dst[..., :coff] == 7).all() and (dst[..., coff + 40:] == 7).all()
 
 
+BIAS_MAP_CASES = [
+    # (B, Cin, Cout, H, W, k, stride, groups, algo)
+    (3, 32, 512, 32, 32, 3, 2, 1, 'direct'),         # tower entry: 3x3 stride 2 (conv_ws2)
+    (3, 32, 256, 16, 32, 3, 1, 1, 'winograd2d'),     # contact conv: one 32-channel chunk (conv_wino2)
+    (2, 48, 256, 16, 32, 3, 1, 1, 'winograd24'),     # HRNet-W48 contact conv (conv_wino24)
+    (3, 48, 96, 20, 24, 3, 2, 1, 'direct'),          # ragged tiles, stride 2
+    (2, 24, 40, 9, 13, 3, 1, 1, 'winograd2d'),       # ragged everything: the element-wise epilogue
+    (2, 24, 40, 9, 13, 3, 1, 1, 'direct'),
+    (2, 64, 96, 16, 16, 1, 1, 1, 'direct'),          # 1x1
+    (2, 16, 24, 12, 16, 3, 1, 2, 'winograd'),        # groups: the map covers groups * Cout channels
+]
+
+
+@pytest.mark.parametrize('case', BIAS_MAP_CASES, ids=lambda c: 'map_B%d_%dto%d_%dx%d_k%ds%dg%d_%s' % c)
+def test_conv2d_position_bias_map(ops, case):
+    """ACRMI_CONV_BIAS_MAP: ONE [Ho,Wo,C] map added to every frame before the ReLU (the coordinate channels of the head
+    convs folded into a per-pixel bias, packer.coord_bias_map) - every conv kernel that takes a residual."""
+    B, cin, cout, H, W, k, stride, groups, algo = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, cin * groups, H, W, generator=g)
+    w = torch.randn(cout * groups, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout * groups, generator=g) * 0.1
+    ref0 = F.conv2d(x.double(), w.double(), b.double(), stride, k // 2, 1, groups)
+    m = torch.randn(1, cout * groups, ref0.shape[2], ref0.shape[3], generator=g)
+    ref = F.relu(ref0 + m.double())
+    out = ops.conv2d(ops.to_nhwc(x), w, b, stride=stride, relu=True, groups=groups, cin=cin, residual=ops.to_nhwc(m), algo=algo)
+    assert (_nchw(out, cout * groups).double() - ref).abs().max().item() < 5e-5
+    # (and the same call with a per-frame residual still means a per-frame residual)
+    r = torch.randn(B, cout * groups, ref0.shape[2], ref0.shape[3], generator=g)
+    out = ops.conv2d(ops.to_nhwc(x), w, b, stride=stride, relu=True, groups=groups, cin=cin, residual=ops.to_nhwc(r), algo=algo)
+    assert (_nchw(out, cout * groups).double() - F.relu(ref0 + r.double())).abs().max().item() < 5e-5
+
+
+def test_conv2d_position_bias_map_rejected_by_the_lds_tap_kernel(ops):
+    x = torch.zeros(2, 16, 32, 32, device='cuda')
+    with pytest.raises(Exception):
+        ops.conv2d(x, torch.zeros(32, 32, 3, 3), None, residual=torch.zeros(1, 16, 32, 32, device='cuda'), algo='winograd2d_lds')
+
+
 def test_conv_stride2_groups_and_slices(ops):
     g = torch.Generator().manual_seed(12)
     x = torch.randn(2, 64, 20, 24, generator=g)

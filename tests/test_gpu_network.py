@@ -219,6 +219,30 @@ def test_parallel_lanes_are_bit_identical(engine, frames2):
         engine.set_lanes(0)
 
 
+def test_tune_lanes_picks_a_measured_candidate_and_keeps_the_results(engine, frames2):
+    """Engine.tune_lanes: lane count and assignment (structural / planned from measured op times, ACRMI_OPT_LANE_PLAN)
+    are chosen by timing the candidates in the process's actual stream state; the winner is one of them and the outputs do
+    not depend on the choice - checked for every candidate, planned schedules included."""
+    x = torch.from_numpy(frames2).cuda()
+    engine.set_lanes(1)
+    want = {k: v.clone() for k, v in engine.forward(x).items()}
+    try:
+        best, ms = engine.tune_lanes(1, candidates=(1, 2, 4), calls=3)
+        assert set(ms) == {(1, False), (2, False), (2, True), (4, False), (4, True)}
+        assert best in ms and ms[best] == min(ms.values())
+        assert engine.lanes == (0 if best[0] == 4 else best[0]) and engine.lane_plan == best[1]
+        for n, planned in ms:
+            engine.set_lane_plan(planned)
+            engine.set_lanes(n)
+            for rep in range(2):
+                out = engine.forward(x)
+                for k in want:
+                    assert torch.equal(out[k], want[k]), (n, planned, rep, k)
+    finally:
+        engine.set_lane_plan(True)
+        engine.set_lanes(0)
+
+
 def test_full_size_batch64_properties(synth_sd, mano_tables, frames2):
     """BASELINE.json's bench configuration (batch 64, 512x512): size-independent properties of the whole path.
     Frames are independent, so (i) the two golden frames planted anywhere in the batch of 64 reproduce the reference's

@@ -102,3 +102,31 @@ def test_planted_center_peaks_are_where_they_were_planted(frame):
     _, lp, rp = cases.INTERIOR_CASES['mid']
     assert s['flag'].tolist() == [[True, True]]
     assert s['flat_ind'].tolist() == [[lp[0] * 64 + lp[1], rp[0] * 64 + rp[1]]]
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_coord_bias_map_is_the_convolution_of_the_coordinate_channels(stride):
+    """packer.coord_bias_map == conv3x3(coordinate maps of the reference's get_coord_maps, acr/model.py:340-369, restated
+    in oracle/acr_net.coord_maps) with the coordinate channels' filter columns, zero padding included; and the lowered
+    fp32 program really drops those channels from the two head convs (Cin 34 -> 32) while the 16-bit one keeps them."""
+    import torch.nn.functional as F
+    packer = pkg('packer')
+    rs = np.random.RandomState(5)
+    wc = rs.randn(24, 2, 3, 3)
+    got = packer.coord_bias_map(wc, 128, stride)
+    cm = acr_net.coord_maps(128).double()                                  # [1,2,128,128]: x, y
+    ref = F.conv2d(cm, torch.from_numpy(wc), None, stride, 1)[0].permute(1, 2, 0).numpy()
+    assert got.shape == (ref.shape[0], ref.shape[1], 24)
+    assert np.abs(got - ref).max() < 1e-12
+
+
+def test_fp32_program_takes_the_coordinate_channels_as_a_bias_map(synth_sd):
+    packer, L = pkg('packer'), pkg('_lib')
+    for precision, want_cin, want_flag in (('fp32', 32, L.CONV_BIAS_MAP), ('fp16', 34, 0)):
+        prog = packer.lower(synth_sd, precision=precision, point_heads=False)
+        ops = {i['name']: o for o, i in zip(prog['ops'], prog['op_info'])}
+        for name in ('towers.entry', 'contact_layers.1.0'):
+            assert ops[name].cin == want_cin and (ops[name].flags & L.CONV_BIAS_MAP) == want_flag, (precision, name)
+        # the FLOP figure of the line keeps the reference's 34 input channels
+        info = {i['name']: i for i in prog['op_info']}
+        assert abs(info['contact_layers.1.0']['flops'] - 2.0 * 128 * 128 * 256 * 34 * 9) < 1.0
