@@ -9,9 +9,10 @@ LIB_PATH = os.environ.get('ACRMI_LIB') or os.path.join(HERE, 'libacrmi.so')   # 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV / acrmi_conv2d's algo: ACRMI_CONV_BIAS_MAP
+CONV_SPLITK = 16       # acrmi_op.flags of a CONV: ACRMI_CONV_SPLITK
 OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF, OPT_MANO_FP16 = 1, 2, 3, 4, 5, 6, 7
 OPT_LANE_PLAN = 8
-VERSION = 300
+VERSION = 301
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
@@ -46,7 +47,7 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_fuse_sum', 'acrmi_attpool', 'acrmi_attpool_ws_floats', 'acrmi_stem_conv', 'acrmi_stream_create', 'acrmi_stream_destroy', 'acrmi_profile_ops', 'acrmi_tune', 'acrmi_preprocess', 'acrmi_cam_trans',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias',
-           'acrmi_buffer_dtype', 'acrmi_conv2d_h16']
+           'acrmi_buffer_dtype', 'acrmi_conv2d_h16', 'acrmi_conv2d_splitk', 'acrmi_conv2d_splitk_workspace']
 
 _lib = None
 
@@ -91,6 +92,10 @@ def lib():
                                i32, i32, i32, i32, i32, i32, vp]
     L.acrmi_conv2d_h16.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, f32p, i32, vp, i32, i32, vp, i32, i32,
                                    i32, i32, i32, i32, i32, i32, i32, vp]
+    L.acrmi_conv2d_splitk.argtypes = [f32p, i32, i32, i32, i32, i32, i32, i32, f32p, f32p, f32p, i32, i32, f32p, i32, i32,
+                                      i32, i32, vp, C.c_size_t, vp]
+    L.acrmi_conv2d_splitk_workspace.argtypes = [i32, i32, i32, i32, i32]
+    L.acrmi_conv2d_splitk_workspace.restype = C.c_size_t
     L.acrmi_buffer_dtype.argtypes = [vp, i32]
     L.acrmi_u8norm.argtypes = [u8p, i32, f32p, vp]
     L.acrmi_bilinear2x.argtypes = [f32p, i32, i32, i32, i32, i32, f32p, i32, vp]

@@ -56,6 +56,11 @@ struct acrmi_ctx {
   hipStream_t lanes[MAX_LANES] = {};
   hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {};
   std::vector<hipEvent_t> op_ev;
+  // split-K convolutions (ACRMI_CONV_SPLITK): partial tiles + arrival counters, one set per lane (ops of one lane are
+  // stream-ordered; ops of different lanes may overlap)
+  float* split_ws[MAX_LANES] = {};
+  unsigned* split_cnt[MAX_LANES] = {};
+  size_t split_ws_floats = 0, split_counters = 0;
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
   float* mano_allocs[2][9] = {};   // 6 fp32 tables + 3 f16 copies per side
@@ -142,6 +147,12 @@ static void free_program(acrmi_ctx* c) {
   c->buf_ptr.clear();
   c->bufs.clear();
   c->ops.clear();
+  for (int l = 0; l < MAX_LANES; ++l) {
+    if (c->split_ws[l]) (void)hipFree(c->split_ws[l]);
+    if (c->split_cnt[l]) (void)hipFree(c->split_cnt[l]);
+    c->split_ws[l] = nullptr; c->split_cnt[l] = nullptr;
+  }
+  c->split_ws_floats = c->split_counters = 0;
   if (c->att_ws) (void)hipFree(c->att_ws);
   c->att_ws = nullptr;
   if (c->picks) (void)hipFree(c->picks);
@@ -180,7 +191,7 @@ int acrmi_load_weights(acrmi_ctx* c, const float* blob, size_t n) {
   return ACRMI_OK;
 }
 
-static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s) {
+static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s, int lane = 0) {
   auto ptr = [&](int id) -> float* { return id >= 0 ? c->buf_ptr[id] : nullptr; };
   auto desc = [&](int id) -> const acrmi_buffer_desc& { return c->bufs[id]; };
   // buffer `id` advanced by `coff` ELEMENTS of its storage type (the pointers stay typed float*: they are opaque here)
@@ -217,6 +228,9 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
       a.in_cs = di.cs; a.in_coff = op.in_coff; a.Cin = op.cin;
       a.out_cs = dout.cs; a.out_coff = op.out_coff; a.Cout = op.cout;
       a.res_cs = op.res_buf >= 0 ? desc(op.res_buf).cs : 0; a.res_coff = op.res_coff;
+      if (op.flags & ACRMI_CONV_SPLITK) {     // groups = K-slices of one convolution; workspace of the lane this op runs on
+        a.splitk = 1; a.split_ws = c->split_ws[lane]; a.split_cnt = c->split_cnt[lane];
+      }
       if (op.flags & ACRMI_CONV_BIAS_MAP) {   // position-bias map in the weight blob, added to every frame
         a.res = c->weights + op.w_off2; a.res_cs = (op.groups * op.cout + 3) / 4 * 4; a.res_coff = 0; a.res_bcast = 1;
       }
@@ -494,9 +508,13 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         return fail(c, ACRMI_EINVAL, "op %d: conv buffer types do not fit (in %d, out %d, algo %d)", i, idt, odt, algo);
       if (op.res_buf >= 0 && bufs[op.res_buf].dtype != odt)
         return fail(c, ACRMI_EINVAL, "op %d: the residual must have the type of the output", i);
+      const bool splitk = (op.flags & ACRMI_CONV_SPLITK) != 0;
+      if (splitk && (algo != 2 || idt || op.groups < 2 || op.groups > 8 || op.cin % 32 || op.cin < 64 || op.cout == 33 ||
+                     op.bias_per_frame))
+        return fail(c, ACRMI_EINVAL, "op %d: split-K needs algo 2, fp32, 2..8 slices of Cin %% 32 == 0, Cin >= 64 channels each", i);
       if (op.flags & ACRMI_CONV_BIAS_MAP) {
         const long long mcs = (op.groups * op.cout + 3) / 4 * 4;
-        if (op.res_buf >= 0 || idt || algo == 3 || !w_ok(op.w_off2, (long long)bufs[op.out_buf].h * bufs[op.out_buf].w * mcs))
+        if (splitk || op.res_buf >= 0 || idt || algo == 3 || !w_ok(op.w_off2, (long long)bufs[op.out_buf].h * bufs[op.out_buf].w * mcs))
           return fail(c, ACRMI_EINVAL, "op %d: a position-bias map needs an fp32 conv without a residual buffer (not algo 3) and "
                       "[Ho][Wo][round4(groups*Cout)] floats inside the blob at w_off2", i);
       }
@@ -507,8 +525,9 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       if (algo == 3 && (op.groups != 1 || op.cin > 32 || op.cout != 32 || op.bias_per_frame || bufs[op.out_buf].h % 8 ||
                         bufs[op.out_buf].w % 16 || op.out_coff % 4 || op.res_coff % 4))
         return fail(c, ACRMI_EINVAL, "op %d: algo 3 needs groups 1, Cin <= 32, Cout = 32, a map of 8x16-pixel tiles", i);
-      if (op.in_coff + op.groups * op.cin > bufs[op.in_buf].cs || op.out_coff + op.groups * op.cout > bufs[op.out_buf].cs ||
-          (op.res_buf >= 0 && op.res_coff + op.groups * op.cout > bufs[op.res_buf].cs) || (op.groups > 1 && op.cin % 4))
+      const int ogroups = splitk ? 1 : op.groups;      // the slices of a split-K conv share the output channels
+      if (op.in_coff + op.groups * op.cin > bufs[op.in_buf].cs || op.out_coff + ogroups * op.cout > bufs[op.out_buf].cs ||
+          (op.res_buf >= 0 && op.res_coff + ogroups * op.cout > bufs[op.res_buf].cs) || (op.groups > 1 && op.cin % 4))
         return fail(c, ACRMI_EINVAL, "op %d: channel slice outside its buffer's channel stride", i);
       const int pad = op.ksize / 2;
       const int ho = (bufs[op.in_buf].h + 2 * pad - op.ksize) / op.stride + 1, wo = (bufs[op.in_buf].w + 2 * pad - op.ksize) / op.stride + 1;
@@ -598,6 +617,19 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
     if (e != hipSuccess) return fail(c, ACRMI_ENOMEM, "hipMalloc(%zu) for buffer %d: %s", bytes, i, hipGetErrorString(e));
     HIPCHK(c, hipMemset(c->buf_ptr[i], 0, bytes));
   }
+  for (int i = 0; i < n_ops; ++i) {
+    const acrmi_op& op = ops[i];
+    if (op.kind != ACRMI_OP_CONV || !(op.flags & ACRMI_CONV_SPLITK)) continue;
+    const auto& d = bufs[op.out_buf];
+    c->split_ws_floats = std::max(c->split_ws_floats, conv_splitk_ws_floats(max_batch, d.h, d.w, op.cout, op.groups));
+    c->split_counters = std::max(c->split_counters, conv_splitk_counters(max_batch, d.h, d.w, op.cout));
+  }
+  if (c->split_ws_floats)
+    for (int l = 0; l < MAX_LANES; ++l) {
+      HIPCHK(c, hipMalloc(&c->split_ws[l], c->split_ws_floats * sizeof(float)));
+      HIPCHK(c, hipMalloc(&c->split_cnt[l], c->split_counters * sizeof(unsigned)));
+      HIPCHK(c, hipMemset(c->split_cnt[l], 0, c->split_counters * sizeof(unsigned)));
+    }
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
   HIPCHK(c, hipMalloc(&c->picks, (size_t)max_batch * 4 * sizeof(int)));
@@ -696,7 +728,7 @@ static int run_program_lanes(acrmi_ctx* c, const uint8_t* img, int B, hipStream_
     hipStream_t s = st(S.lane[j]);
     static const int ablate = getenv("ACRMI_ABLATE_LANE_SYNC") ? atoi(getenv("ACRMI_ABLATE_LANE_SYNC")) : 0;   // timing ablation (WRONG results): 1 = no waits, 2 = no waits and no records
     if (!(ablate & 1)) for (int d : S.wait[j]) HIPCHK(c, hipStreamWaitEvent(s, c->op_ev[d], 0));
-    r = run_op(c, c->ops[j], img, B, s);
+    r = run_op(c, c->ops[j], img, B, s, S.lane[j]);
     if (r) break;
     if (S.signal[j] && !(ablate & 2)) {
       if (!c->op_ev[j]) HIPCHK(c, hipEventCreateWithFlags(&c->op_ev[j], lane_event_flags()));
@@ -1009,6 +1041,43 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   a.bias_fstride = bias_frame_stride;
   a.algo = algo;
   a.res_bcast = bias_map ? 1 : 0;
+  hipError_t e = launch_conv(a, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
+  return ACRMI_OK;
+}
+
+size_t acrmi_conv2d_splitk_workspace(int B, int H, int W, int cout, int splits) {
+  if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || splits < 2) return 0;
+  const size_t cnt = (conv_splitk_counters(B, H, W, cout) * sizeof(unsigned) + 255) / 256 * 256;
+  return cnt + conv_splitk_ws_floats(B, H, W, cout, splits) * sizeof(float);
+}
+
+int acrmi_conv2d_splitk(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin_slice, int splits,
+                        const float* w_packed, const float* bias, const float* res, int res_cs, int res_coff, float* out,
+                        int out_cs, int out_coff, int cout, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!in || !w_packed || !bias || !out || !workspace || B <= 0 || H <= 0 || W <= 0 || cout <= 0)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_splitk: bad arguments");
+  if (splits < 2 || splits > 8 || cin_slice < 64 || cin_slice % 32 || cout == 33)
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_splitk: 2..8 slices of >= 64 channels (a multiple of 32) each; Cout != 33");
+  if (in_cs % 4 || in_coff % 4 || in_coff < 0 || out_coff < 0 || res_coff < 0 || in_coff + splits * cin_slice > in_cs ||
+      out_coff + cout > out_cs || (res && res_coff + cout > res_cs))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_splitk: channel slice outside its tensor's channel stride");
+  if (workspace_bytes < acrmi_conv2d_splitk_workspace(B, H, W, cout, splits) || ((uintptr_t)workspace & 15))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_splitk: workspace too small (acrmi_conv2d_splitk_workspace) or unaligned");
+  ConvArgs a{};
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = res; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W;
+  a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = cin_slice;
+  a.out_cs = out_cs; a.out_coff = out_coff; a.Cout = cout;
+  a.res_cs = res_cs; a.res_coff = res_coff;
+  a.ks = 3; a.stride = 1; a.relu = relu; a.groups = splits;
+  a.cin8 = cin_slice / 8;
+  a.n_tiles = cout <= 32 ? 1 : ((cout + 63) / 64) * 2;
+  a.algo = 2;
+  a.splitk = 1;
+  a.split_cnt = reinterpret_cast<unsigned*>(workspace);
+  a.split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
+                                        (conv_splitk_counters(B, H, W, cout) * sizeof(unsigned) + 255) / 256 * 256);
   hipError_t e = launch_conv(a, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "conv launch: %s", hipGetErrorString(e));
   return ACRMI_OK;

@@ -8,6 +8,7 @@ namespace acrmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));   // data operand of the raw buffer store builtins
 
 // host-side state shared by the launchers of both translation units (defined in conv_mfma.hip)
 int conv_forced_cfg();                 // acrmi_tune key 0 (-1 = automatic)

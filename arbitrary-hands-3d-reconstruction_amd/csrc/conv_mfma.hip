@@ -562,10 +562,12 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   if (a.dtype != ACRMI_DT_F32) return launch_conv_h16(a, s);   // f16 / bf16 storage: conv_h16.hip
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
+  if (a.splitk && a.algo != 2) return hipErrorInvalidValue;
   if (a.algo == 4) return launch_wino24(a, s);  // F(2x4,3x3): weights packed with 4x6 taps
   if (a.algo == 3) return launch_wino3(a, s);   // F(2x2,3x3), Cin <= 32, Cout = 32: weights packed for LDS residency
   if (a.algo == 2) {   // Winograd F(2x2,3x3): 3x3 stride 1 only, weights packed with 16 taps
     if (a.ks != 3 || a.stride != 1) return hipErrorInvalidValue;
+    if (a.splitk) return launch_wino2<1, 32, 2>(a, s);      // K-slices as groups, one n-tile per item (conv_wino2.inc SPLIT)
     // two n-tiles per wave need two Cin chunks per item (single-buffered exchange area); Cin <= 32 runs one
     // n-tile per wave and one 32-cout block per work item instead
     // Cout = 33 with more than one Cin chunk: one regular tile + the 33rd channel on 4x4x1 MFMAs (conv_wino2.inc ODD)

@@ -33,7 +33,19 @@ struct ConvArgs {
   int dtype;
   int out_f32;          // 16-bit input, fp32 output and fp32 residual (the head exits)
   int res_bcast;        // 1: res is ONE [Ho][Wo][res_cs] map added to every frame (not conv_wino3 / the 16-bit kernels)
+  // Split-K (algo 2, small batches; conv_wino2.inc SPLIT): groups = K-slices of one convolution (slice s reads input
+  // channels [s*Cin, (s+1)*Cin), all slices produce the same Cout channels).  split_ws: conv_splitk_ws_floats() floats,
+  // split_cnt: conv_splitk_counters() zeroed unsigned, both private to the launches of one stream.
+  int splitk;
+  float* split_ws;
+  unsigned* split_cnt;
 };
+// workspace of a split-K launch: (8x16-pixel tiles) x (32-cout blocks) groups of `splits` partial tiles of 4096 floats
+inline size_t conv_splitk_groups(int B, int Ho, int Wo, int cout) {
+  return (size_t)B * ((Ho + 7) / 8) * ((Wo + 15) / 16) * (cout <= 32 ? 1 : ((cout + 63) / 64) * 2);
+}
+inline size_t conv_splitk_ws_floats(int B, int Ho, int Wo, int cout, int splits) { return conv_splitk_groups(B, Ho, Wo, cout) * splits * 4096; }
+inline size_t conv_splitk_counters(int B, int Ho, int Wo, int cout) { return conv_splitk_groups(B, Ho, Wo, cout) * 4; }
 
 // one-time per-DEVICE kernel setup (dynamic LDS attribute): true the first time `flags` (one static array per kernel
 // instantiation) is asked about the current device

@@ -53,17 +53,20 @@ class Engine(object):
 
     # ---- setup ---------------------------------------------------------------------------------
     def load_state_dict(self, sd, max_batch=1, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False,
-                        wino24='auto'):
+                        wino24='auto', splitk='auto'):
         """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
         keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`).
         precision: 'fp32' | 'fp16' | 'bf16' (args().model_precision, acr/config.py:96; packer.lower).
-        wino24: 'auto' (F(2x4,3x3) for contexts of max_batch >= 16), True / False to force (packer.lower)."""
+        wino24: 'auto' (F(2x4,3x3) for contexts of max_batch >= 16), True / False to force (packer.lower).
+        splitk: 'auto' (split-K lowering of the low-resolution 3x3 layers for contexts of max_batch < 16), True / False."""
         # F(2x4,3x3) is a large-batch choice: its items (8x32 pixels x one n-tile) are half as many as conv_wino2's
         # small-batch items, which costs latency when a launch cannot fill the CUs anyway (batch 1: 3.7 vs 3.5 ms)
+        small = max_batch < 16        # single-frame / small-batch context: latency lowering (packer.lower)
         if wino24 == 'auto':
-            wino24 = None if max_batch >= 16 else False
+            wino24 = None if not small else False
         self.load_program(packer.lower(sd, keep_taps=keep_taps, precision=precision, keep_weights=keep_weights,
-                                       keep_all=keep_all, wino24=wino24), max_batch)
+                                       keep_all=keep_all, wino24=wino24, splitk=small if splitk == 'auto' else splitk),
+                          max_batch)
 
     def load_program(self, prog, max_batch=1):
         """A program lowered elsewhere (packer.lower, or another Engine's `program`): the same packed weights and op
@@ -414,7 +417,8 @@ class EnginePool(object):
         checkpoint at the same max_batch lowers to the same program on an Engine and on a pool: bit-equal results)."""
         if wino24 == 'auto':
             wino24 = None if max_batch >= 16 else False
-        prog = self.engines[0].program if sd is None else packer.lower(sd, precision=precision, wino24=wino24)
+        prog = self.engines[0].program if sd is None else packer.lower(sd, precision=precision, wino24=wino24,
+                                                                       splitk=max_batch < 16)
         if prog is None:
             raise _lib.AcrmiError('no checkpoint loaded')
         for e in self.engines:

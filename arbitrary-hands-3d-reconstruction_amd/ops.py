@@ -82,6 +82,37 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     return out
 
 
+def conv2d_splitk(x, weight, bias=None, splits=2, relu=False, residual=None, in_coff=0, out=None, out_coff=0, out_cs=None,
+                  workspace=None):
+    """3x3 stride-1 convolution as Winograd F(2x2,3x3) with the input channels split into `splits` slices that run as
+    separate work items and meet in `workspace` (acrmi_conv2d_splitk; the small-batch form of the low-resolution HRNet
+    branches).  x NHWC fp32 [B,H,W,cs]; weight [Cout, Cin, 3, 3] with Cin = splits * (a multiple of 32, >= 64).
+    workspace: zeroed uint8 device tensor of conv2d_splitk_workspace() bytes (allocated here when None)."""
+    _need_cuda(x, residual, out, workspace)
+    w = weight.detach().cpu().numpy() if hasattr(weight, 'detach') else np.asarray(weight)
+    cout, cin, k, _ = w.shape
+    if k != 3 or cin % splits:
+        raise ValueError('split-K needs a 3x3 convolution whose Cin is a multiple of the slice count')
+    ks = cin // splits
+    b = np.zeros(cout, np.float32) if bias is None else (
+        bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
+    packed = [pack_conv(winograd2d_weights(w[:, s * ks:(s + 1) * ks].astype(np.float64)), b) for s in range(splits)]
+    wp = torch.from_numpy(np.concatenate([p[0] for p in packed])).to(x.device)
+    bp = torch.from_numpy(np.concatenate([p[1] for p in packed])).to(x.device)
+    B, H, W, cs = x.shape
+    if out is None:
+        out_cs = out_cs or (cout + 3) // 4 * 4
+        out = torch.zeros(B, H, W, out_cs, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    need = int(L.acrmi_conv2d_splitk_workspace(B, H, W, cout, splits))
+    if workspace is None:
+        workspace = torch.zeros(need, dtype=torch.uint8, device=x.device)
+    _lib.check(L.acrmi_conv2d_splitk(_p(x), B, H, W, cs, in_coff, ks, splits, _p(wp), _p(bp), _p(residual),
+                                     residual.shape[-1] if residual is not None else 0, 0, _p(out), out.shape[-1], out_coff,
+                                     cout, int(relu), _p(workspace), workspace.numel(), _s(x)))
+    return out
+
+
 def to_nhwc16(x_nchw, precision='fp16', cs=None, device='cuda'):
     """[B,C,H,W] float (any device) -> contiguous NHWC float16 / bfloat16 on `device`, channel stride cs (a multiple
     of 8, zero padded): the activation layout of a 16-bit program."""

@@ -231,6 +231,23 @@ def coord_bias_map(wc, size, stride):
     return out
 
 
+# Split-K (ACRMI_CONV_SPLITK; small-batch programs only - Engine.load_state_dict asks for it below 16 frames): a 3x3
+# stride-1 Winograd layer whose launch would be at most SPLITK_MAX_ITEMS work items on one frame is lowered with its input
+# channels in 64-channel slices that run as separate items (256 -> 256 at 16x16: 16 items of 8 chunks -> 64 of 2; 128 ->
+# 128 at 32x32: 32 of 4 -> 64 of 2).  tools/critical_path.py: at batch 1 these layers ARE the dependency chain the call's
+# latency follows (24 launches of 31 us + 32 of 20 us of its 2.4 ms).
+SPLITK_MAX_ITEMS = 32
+
+
+def splitk_slices(k, stride, cin, cout, groups, ho, wo, per_frame_bias):
+    """number of K-slices a small-batch program gives this conv (1 = not split)"""
+    if not (k == 3 and stride == 1 and groups == 1 and not per_frame_bias and cout != 33 and cin >= 128 and cin % 64 == 0):
+        return 1
+    n_tiles = 1 if cout <= 32 else (cout + 63) // 64 * 2
+    items = ((ho + 7) // 8) * ((wo + 15) // 16) * n_tiles
+    return min(cin // 64, 8) if items <= SPLITK_MAX_ITEMS else 1
+
+
 # layer1.0's projection shortcut as extra input channels of its last 1x1 conv (Program.bottleneck): batch 64, fp32:
 # downsample 0.46 ms + conv3 0.51 ms -> one 128 -> 256 conv.
 FUSE_PROJECTION = True
@@ -264,10 +281,11 @@ class Blob(object):
 class Program(object):
     """Op list + buffer table under construction."""
 
-    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None):
+    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None, splitk=False):
         self.sd = {k: _np(v) for k, v in sd.items()}
         self.dt = dt             # storage type of the activations between layers (DT_*); head outputs stay fp32
         self.keep_weights = keep_weights
+        self.splitk = splitk      # small-batch program: split-K lowering of the low-resolution 3x3 layers
         self.wino24 = wino24      # None = packer.WINOGRAD_24
         self.keep_all = keep_all  # no lifetime-based buffer reuse: every intermediate map survives the run (tests)
         self.blob = Blob()
@@ -365,8 +383,17 @@ class Program(object):
             bp = np.zeros(32, b0.dtype)
             bp[:cout] = b0
             wb_list, cout = [(wp, bp)], 32
+        slices = 1
+        if self.splitk and self.dt == DT_F32 and bias_map is None and len(wb_list) == 1:
+            slices = splitk_slices(k, stride, cin, cout, 1, ho, wo, bias_buf is not None)
+            if slices > 1 and conv_algo(k, stride, cin, cout, 1, ho, wo, bias_buf is not None, False) != 2:
+                slices = 1
+        if slices > 1:      # K-slices as the "groups" of the op: slice s = input channels [s*ks, (s+1)*ks), same Cout
+            w0, b0 = wb_list[0]
+            ks = cin // slices
+            wb_list, cin = [(w0[:, s * ks:(s + 1) * ks], b0) for s in range(slices)], ks
         if out is None:
-            out = self.buf(ho, wo, (out_c or cout * len(wb_list)))
+            out = self.buf(ho, wo, (out_c or (cout if slices > 1 else cout * len(wb_list))))
         if self.dt != DT_F32:
             # 16-bit program: every conv is the direct f16 / bf16 MFMA kernel (the matrix pipe is 16x faster than
             # in fp32 and the layers are HBM-bound: Winograd would only add arithmetic error).  A residual has the
@@ -377,7 +404,7 @@ class Program(object):
             packed = [pack_conv_h16(w, b, self.dt) for (w, b) in wb_list]
             w_off = self.blob.add16(np.concatenate([p[0] for p in packed]))
         else:
-            algo = conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24)
+            algo = 2 if slices > 1 else conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24)
             if algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:
@@ -385,11 +412,14 @@ class Program(object):
                 packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
             w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
-        flops = 2.0 * ho * wo * flop_cout * cin_w * k * k * len(wb_list)     # algorithmic (direct-conv) FLOPs
+        flops = 2.0 * ho * wo * flop_cout * cin_w * k * k * (1 if slices > 1 else len(wb_list))     # algorithmic (direct-conv) FLOPs
         self._op(name, flops, kind=_lib.OP_CONV, in_buf=src, out_buf=out, res_buf=-1 if res is None else res,
                  in_coff=in_coff, out_coff=out_coff, res_coff=res_coff, cin=cin, cout=cout, ksize=k, stride=stride,
                  relu=int(relu), groups=len(wb_list), w_off=w_off, b_off=b_off, flags=algo,
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
+        if slices > 1:
+            self.ops[-1].flags = algo | _lib.CONV_SPLITK
+            self.op_info[-1]['algo'] = 'winograd_f2x2_3x3_splitk%d' % slices
         if bias_map is not None:
             assert res is None and self.dt == DT_F32 and algo != 3
             assert bias_map.shape == (ho, wo, (cout * len(wb_list) + 3) // 4 * 4), bias_map.shape
@@ -520,7 +550,7 @@ def point_tower(P, side, k):
 
 
 def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False,
-          wino24=None):
+          wino24=None, splitk=False):
     """state dict -> dict(blob, bufs, ops, heads, op_info, taps, precision, width).  See module docstring.
     point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT; fp32 W32 only).
     keep_taps: pin the buffers of the backbone taps the golden vectors hold (stem / layer1 / stage2 / stage3 branch 0,
@@ -535,6 +565,8 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     keep_weights: op_info[i]['wb'] keeps the folded fp64 filters of every conv (oracle/program.py, tests only).
     wino24: None = packer.WINOGRAD_24 (on); False lowers the 3x3 stride-1 layers with Cin > 32 to F(2x2,3x3) - what
     Engine.load_state_dict asks for when max_batch < 16 (single-frame / small-batch latency: batch 1 3.5 vs 3.7 ms).
+    splitk: small-batch program (Engine.load_state_dict: max_batch < 16) - the low-resolution 3x3 layers are lowered
+    with their input channels in slices that run as separate work items (ACRMI_CONV_SPLITK, splitk_slices()).
     keep_all: no buffer is reused, so every intermediate map can be read after a run (per-op parity tests; ~2x the
     activation memory)."""
     sd = strip_prefix(sd)
@@ -547,7 +579,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     c0 = width
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
-    P = Program(sd, dt, keep_weights, keep_all, wino24)
+    P = Program(sd, dt, keep_weights, keep_all, wino24, splitk)
     b = 'backbone.'
     # ---- stem -----------------------------------------------------------------------------------
     w, bb = P.folded(b + 'conv1', b + 'bn1')

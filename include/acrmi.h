@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ACRMI_VERSION 300
+#define ACRMI_VERSION 301
 
 #define ACRMI_OK 0
 #define ACRMI_EINVAL (-1)  /* bad argument / unsupported shape  (reference: ValueError / assert) */
@@ -78,6 +78,14 @@ enum {
  * of the reference's head convs (acr/model.py:52,340-369) leave the contraction (34 -> 32 input channels) and come back
  * as conv(coord maps, their filter columns), computed once at lowering time (packer.coord_bias_map). */
 #define ACRMI_CONV_BIAS_MAP 8
+/* acrmi_op.flags of a CONV, bit 4: split-K (algo 2, fp32, small-batch programs).  `groups` K-slices of ONE convolution:
+ * slice s reads input channels [in_coff + s*cin, in_coff + (s+1)*cin) with its own packed filters (w_off: `groups`
+ * consecutive pack_conv(winograd2d_weights(w[:, s*cin:(s+1)*cin])), b_off: `groups` bias rows of which the first is
+ * used), all slices produce the same cout channels.  The slices are separate work items on separate CUs; their partial
+ * tiles meet in a workspace of the context and are summed in slice order by whichever item arrives last (bit-reproducible
+ * results).  cin % 32 == 0, cin >= 64, 2 <= groups <= 8.  What it is for: a 256 -> 256 layer on a 16x16 map is 16 work
+ * items of 8 chunks for 256 CUs at batch 1 - 64 items of 2 chunks with 4 slices. */
+#define ACRMI_CONV_SPLITK 16
 
 /* acrmi_op.mode: which variant of the head program an op belongs to. */
 enum {
@@ -213,6 +221,15 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
  * of v_mfma_f32_32x32x16_{f16,bf16}), bias fp32.  fp32 accumulation; bias, residual and ReLU in fp32; ONE rounding of
  * the result.  out_f32 != 0: out AND res are fp32 tensors (strides multiples of 4; stride-1 shapes only) - the head
  * exits, whose maps the reference converts with .float() (acr/model.py:56-62). */
+/* Split-K form of acrmi_conv2d with algo 2 (see ACRMI_CONV_SPLITK): cin_slice channels per slice, `splits` slices,
+ * w_packed / bias = the slices' pack_conv outputs one after the other.  workspace: acrmi_conv2d_splitk_workspace() bytes
+ * of device memory, 16-byte aligned, ZEROED ONCE by the caller (every launch leaves its counters zero again) and not
+ * shared by launches that may overlap. */
+size_t acrmi_conv2d_splitk_workspace(int B, int H, int W, int cout, int splits);
+int acrmi_conv2d_splitk(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin_slice, int splits,
+                        const float* w_packed, const float* bias, const float* res, int res_cs, int res_coff, float* out,
+                        int out_cs, int out_coff, int cout, int relu, void* workspace, size_t workspace_bytes, void* stream);
+
 int acrmi_conv2d_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int cin, const void* w_packed,
                      const float* bias, int bias_frame_stride, const void* res, int res_cs, int res_coff, void* out,
                      int out_cs, int out_coff, int cout, int ksize, int stride, int relu, int groups, int dtype,

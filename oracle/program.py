@@ -25,6 +25,7 @@ import torch.nn.functional as F
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
 MODE_POINT = 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV (include/acrmi.h)
+CONV_SPLITK = 16
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 
@@ -57,15 +58,20 @@ class Interp(object):
         for (w, b) in info['wb']:
             ws.append(rnd(torch.from_numpy(np.ascontiguousarray(w)), wdt).to(torch.float64))
             bs.append(torch.from_numpy(np.asarray(b, np.float32)).to(torch.float64))    # bias: fp32 in the blob
-        w = torch.cat(ws, 0)
-        y = F.conv2d(x.permute(0, 3, 1, 2).to(torch.float64), w, None, op.stride, op.ksize // 2, 1, op.groups)
+        splitk = bool(op.flags & CONV_SPLITK)          # the "groups" are K-slices of one convolution: same Cout
+        if splitk:
+            w, bs = torch.cat(ws, 1), bs[:1]
+            y = F.conv2d(x.permute(0, 3, 1, 2).to(torch.float64), w, None, op.stride, op.ksize // 2, 1, 1)
+        else:
+            w = torch.cat(ws, 0)
+            y = F.conv2d(x.permute(0, 3, 1, 2).to(torch.float64), w, None, op.stride, op.ksize // 2, 1, op.groups)
         y = y.permute(0, 2, 3, 1)
         if op.bias_per_frame:
             y = y + self.bufs[op.aux_buf][:, 0, 0, :y.shape[-1]].to(torch.float64)[:, None, None, :]
         else:
             y = y + torch.cat(bs)[None, None, None, :]
         y = y.to(torch.float32)                        # the kernels add bias / residual in fp32
-        n = op.groups * op.cout
+        n = op.cout if splitk else op.groups * op.cout
         if op.flags & CONV_BIAS_MAP:                   # position-bias map in the blob: one map for every frame
             ho, wo, cs = y.shape[1], y.shape[2], (n + 3) // 4 * 4
             y = y + self.blob[op.w_off2:op.w_off2 + ho * wo * cs].view(1, ho, wo, cs)[..., :n]

@@ -84,7 +84,7 @@ def test_hostile_checkpoint_against_the_reference_and_per_layer_winograd_error(m
     L = pkg('_lib')
     hs = synth.make_state_dict(seed=0, law='hostile')
     eng = pkg('engine').Engine(0)
-    eng.load_state_dict(hs, max_batch=2, keep_weights=True, keep_all=True, wino24=True)      # the large-batch lowering
+    eng.load_state_dict(hs, max_batch=2, keep_weights=True, keep_all=True, wino24=True, splitk=False)      # the large-batch lowering
     eng.load_mano(_flip_left(mano_tables))
     g = golden('e2e_batch1.npz')
     x = torch.from_numpy(frames2)
@@ -134,6 +134,32 @@ def test_hostile_checkpoint_against_the_reference_and_per_layer_winograd_error(m
     assert len(wino) >= 200 and sum(r['algo'] == 'winograd_f2x4_3x3' for r in wino) >= 100
     # F(2x2,3x3) in fp32: ~4x the round-off of the direct form, F(2x4,3x3) ~10x; the budget is relative to the layer's largest output
     assert rep['worst_winograd_rel_err'] < 2e-5, rep
+    eng.close()
+
+
+def test_hostile_checkpoint_on_the_small_batch_lowering(mano_tables, frames2):
+    """The same hostile checkpoint on a small-batch context (F(2x2,3x3) everywhere, the low-resolution branches as
+    split-K launches whose partial tiles are summed by the last arriver): decisions identical to the real reference's,
+    vertices / joints within the 1e-4 m budget."""
+    synth = pkg('synth')
+    L = pkg('_lib')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth.make_state_dict(seed=0, law='hostile'), max_batch=2)
+    assert sum(1 for o in eng.program['ops'] if o.kind == L.OP_CONV and o.flags & L.CONV_SPLITK) == 80
+    eng.load_mano(_flip_left(mano_tables))
+    g = golden('e2e_batch1.npz')
+    out = eng.forward(torch.from_numpy(frames2).cuda())
+    torch.cuda.synchronize()
+    slots = out['slots'].cpu().numpy()
+    worst_v = 0.0
+    for b in range(2):
+        np.testing.assert_array_equal(slots[b, :, L.SLOT_FLAG] > 0.5, g['f%d_detection_flag' % b].astype(bool))
+        lc, rc = g['f%d_l_centers_pred' % b][0], g['f%d_r_centers_pred' % b][0]
+        assert slots[b, 0, L.SLOT_FLATIND] == lc[1] * 64 + lc[0] and slots[b, 1, L.SLOT_FLATIND] == rc[1] * 64 + rc[0]
+        worst_v = max(worst_v, float(np.abs(out['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max()),
+                      float(np.abs(out['joints'][b].cpu().numpy() - g['f%d_j3d' % b]).max()))
+    _report('hostile_checkpoint_small_batch_lowering', {'end_to_end_max_vertex_joint_abs_err_m': worst_v})
+    assert worst_v < 1e-4, worst_v
     eng.close()
 
 

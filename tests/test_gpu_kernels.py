@@ -308,6 +308,84 @@ def test_conv2d_position_bias_map_rejected_by_the_lds_tap_kernel(ops):
         ops.conv2d(x, torch.zeros(32, 32, 3, 3), None, residual=torch.zeros(1, 16, 32, 32, device='cuda'), algo='winograd2d_lds')
 
 
+SPLITK_CASES = [
+    # (B, Cin, Cout, H, W, splits, residual)
+    (1, 256, 256, 16, 16, 4, True),      # stage-4 branch 3, one frame: 16 items of 8 chunks -> 64 of 2
+    (1, 128, 128, 32, 32, 2, True),      # branch 2
+    (2, 256, 256, 16, 16, 2, False),
+    (1, 192, 96, 12, 20, 3, True),       # ragged tiles, ragged Cout (HRNet-W48's third branch), three slices
+    (3, 512, 64, 8, 16, 8, False),       # eight slices
+    (8, 256, 256, 16, 16, 4, True),      # more items than CUs: a workgroup takes several (tile, slice) items in turn
+]
+
+
+@pytest.mark.parametrize('case', SPLITK_CASES, ids=lambda c: 'splitk_B%d_%dto%d_%dx%d_s%d_res%d' % c)
+def test_conv2d_splitk_matches_torch_and_is_reproducible(ops, case):
+    """ACRMI_CONV_SPLITK / acrmi_conv2d_splitk: the K-slices of one convolution as separate work items whose partial
+    tiles the last arriver sums in slice order.  Against an fp64 convolution; BIT-equal run after run (the sum order does
+    not depend on who arrives last) with the workspace re-used as the kernel left it; and equal to the unsplit Winograd
+    kernel within fp32 round-off."""
+    B, cin, cout, H, W, splits, with_res = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g) if with_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    ref = F.relu(ref)
+    xd, rd = ops.to_nhwc(x), (ops.to_nhwc(res) if with_res else None)
+    L = pkg('_lib').lib()
+    ws = torch.zeros(int(L.acrmi_conv2d_splitk_workspace(B, H, W, cout, splits)), dtype=torch.uint8, device='cuda')
+    outs = []
+    for rep in range(4):
+        out = ops.conv2d_splitk(xd, w, b, splits=splits, relu=True, residual=rd, workspace=ws)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert (_nchw(outs[0], cout).double() - ref).abs().max().item() < 5e-5
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    plain = ops.conv2d(xd, w, b, relu=True, residual=rd, algo='winograd2d')
+    assert (plain - outs[0]).abs().max().item() < 2e-5
+    # the counters are back to zero: the workspace holds nothing a later launch depends on
+    ncnt = B * ((H + 7) // 8) * ((W + 15) // 16) * (1 if cout <= 32 else (cout + 63) // 64 * 2) * 4
+    assert int(ws[:4 * ncnt].view(torch.int32).abs().sum()) == 0
+
+
+def test_conv2d_splitk_arrival_order_stress(ops):
+    """60 back-to-back launches of the case with more (tile, slice) items than CUs, while a second stream keeps the GPU
+    busy with other work (arrival order of the slices varies): every launch bit-equal to the first."""
+    g = torch.Generator().manual_seed(43)
+    B, cin, cout, H, W, splits = 8, 256, 256, 16, 16, 4
+    x = ops.to_nhwc(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    L = pkg('_lib').lib()
+    ws = torch.zeros(int(L.acrmi_conv2d_splitk_workspace(B, H, W, cout, splits)), dtype=torch.uint8, device='cuda')
+    first = ops.conv2d_splitk(x, w, None, splits=splits, workspace=ws).clone()
+    noise = torch.randn(4096, 4096, device='cuda')
+    side = torch.cuda.Stream()
+    outs = []
+    for rep in range(60):
+        if rep % 3 == 0:
+            with torch.cuda.stream(side):
+                noise = torch.sin(noise)
+        outs.append(ops.conv2d_splitk(x, w, None, splits=splits, workspace=ws).clone())
+    torch.cuda.synchronize()
+    for rep, o in enumerate(outs):
+        assert torch.equal(o, first), rep
+
+
+def test_conv2d_splitk_rejects_what_it_cannot_do(ops):
+    x = torch.zeros(1, 16, 16, 128, device='cuda')
+    with pytest.raises(Exception):
+        ops.conv2d_splitk(x, torch.zeros(64, 128, 3, 3), splits=4)          # 32-channel slices: one chunk per item
+    with pytest.raises(Exception):
+        ops.conv2d_splitk(x, torch.zeros(33, 128, 3, 3), splits=2)          # the 33-channel kernel is not split
+    with pytest.raises(Exception):
+        ops.conv2d_splitk(x, torch.zeros(64, 128, 3, 3), splits=2, workspace=torch.zeros(64, dtype=torch.uint8, device='cuda'))
+
+
 def test_conv_stride2_groups_and_slices(ops):
     g = torch.Generator().manual_seed(12)
     x = torch.randn(2, 64, 20, 24, generator=g)

@@ -130,3 +130,27 @@ def test_fp32_program_takes_the_coordinate_channels_as_a_bias_map(synth_sd):
         # the FLOP figure of the line keeps the reference's 34 input channels
         info = {i['name']: i for i in prog['op_info']}
         assert abs(info['contact_layers.1.0']['flops'] - 2.0 * 128 * 128 * 256 * 34 * 9) < 1.0
+
+
+def test_small_batch_program_splits_the_low_resolution_layers(synth_sd, frame):
+    """packer.lower(splitk=True) (what Engine.load_state_dict asks for below 16 frames): the 3x3 layers of HRNet branches
+    2 (128 channels at 32x32) and 3 (256 at 16x16) become ACRMI_CONV_SPLITK ops - K-slices of 64 channels as the op's
+    "groups", same output channels - and the interpreter, which reads such an op as ONE convolution over the concatenated
+    slices, still agrees with the reference-pinned oracle on every head map."""
+    torch.set_num_threads(8)
+    packer, L = pkg('packer'), pkg('_lib')
+    prog = packer.lower(synth_sd, keep_weights=True, point_heads=False, wino24=False, splitk=True)
+    split = [(o, i) for o, i in zip(prog['ops'], prog['op_info']) if o.kind == L.OP_CONV and o.flags & L.CONV_SPLITK]
+    assert len(split) == 7 * 8 + 3 * 8                       # branch 2 in 7 modules, branch 3 in 3, 8 convs each
+    for o, i in split:
+        assert o.cin == 64 and o.groups in (2, 4) and o.groups * o.cin == o.cout and (o.flags & 7) == 2, i['name']
+        h, w, cs = prog['bufs'][o.out_buf][:3]
+        assert cs == o.cout and (h, w) in ((32, 32), (16, 16))
+        assert abs(i['flops'] - 2.0 * h * w * o.cout * o.cout * 9) < 1.0
+    assert not any(o.flags & L.CONV_SPLITK for o in packer.lower(synth_sd, point_heads=False)['ops'] if o.kind == L.OP_CONV)
+    got = oprog.run_program(prog, frame).head_maps()
+    with torch.no_grad():
+        ref = acr_net.network(synth_sd, frame)
+    for k in ref:
+        err, scale = float((got[k] - ref[k]).abs().max()), float(ref[k].abs().max())
+        assert err < 2e-5 * max(1.0, scale), (k, err, scale)
