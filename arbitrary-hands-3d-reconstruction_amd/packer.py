@@ -419,14 +419,13 @@ class Program(object):
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
         if slices > 1:
             self.ops[-1].flags = algo | _lib.CONV_SPLITK
-            self.op_info[-1]['algo'] = 'winograd_f2x2_3x3_splitk%d' % slices
         if bias_map is not None:
             assert res is None and self.dt == DT_F32 and algo != 3
             assert bias_map.shape == (ho, wo, (cout * len(wb_list) + 3) // 4 * 4), bias_map.shape
             self.ops[-1].flags = algo | _lib.CONV_BIAS_MAP
             self.ops[-1].w_off2 = self.blob.add(bias_map)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
-                                    'winograd_f2x4_3x3')[algo]
+                                    'winograd_f2x4_3x3')[algo] + ('_splitk%d' % slices if slices > 1 else '')
         if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
             self.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for (w, b) in wb_list]
         return out
