@@ -9,7 +9,7 @@ import torch
 
 from ..config import args, validate
 from ..engine import Engine
-from ..schema import state_dict_schema, width_of
+from ..schema import RESNET50, backbone_channels, state_dict_schema, width_of
 from .result_parser import ResultParser, rows_from_slots
 
 
@@ -19,7 +19,7 @@ class ACR(object):
         self._retired = None
         self._result_parser = ResultParser()
         self.params_num = self._result_parser.params_num
-        self._init_sd(int(kwargs.get('width', 32)))
+        self._init_sd(kwargs.get('width', RESNET50 if getattr(self._args, 'backbone', 'hrnet') == RESNET50 else 32))
         self._device = device
         self._max_batch = max_batch
         self._engine = None
@@ -27,7 +27,8 @@ class ACR(object):
         self.training = False
 
     def _init_sd(self, width):
-        """Zero-initialised tensors with the reference's key names (HRNet width 32; 48 = the BASELINE configs[4] variant)."""
+        """Zero-initialised tensors with the reference's key names (HRNet width 32; 48 = the BASELINE configs[4] variant;
+        'resnet50' = the build-defined backbone of configs[1], schema._resnet50_backbone)."""
         self._width = width
         self._sd = OrderedDict()
         for k, shp in state_dict_schema(width).items():       # zero-initialised until a checkpoint is loaded
@@ -43,7 +44,7 @@ class ACR(object):
     def load_state_dict(self, sd, strict=True):
         from ..packer import strip_prefix, check_state_dict
         sd = strip_prefix(sd)
-        if width_of(sd) != self._width and width_of(sd) in (32, 48):
+        if width_of(sd) != self._width and width_of(sd) in (32, 48, RESNET50):
             self._init_sd(width_of(sd))                  # an HRNet-W48 checkpoint re-shapes the module
         if strict:
             check_state_dict(sd)
@@ -108,7 +109,7 @@ class ACR(object):
         """acr/model.py:831-865: uint8 [B,512,512,3] -> [B,32,128,128] (NCHW copy of the resident buffer)."""
         eng = self.engine(image.shape[0])
         B = eng.backbone_heads(image)
-        return eng.buffer(eng.program['heads'].backbone_buf, B, self._width).permute(0, 3, 1, 2).float().contiguous()
+        return eng.buffer(eng.program['heads'].backbone_buf, B, backbone_channels(self._width)).permute(0, 3, 1, 2).float().contiguous()
 
     @torch.no_grad()
     def head_forward(self, image):

@@ -60,9 +60,11 @@ def parse_args(input_args=None):
 
 
 def validate(ns):
-    if ns.backbone != 'hrnet':
-        # the reference only ever builds HRNet-W32 (acr/model.py:27), whatever --backbone says
-        raise ValueError("only the 'hrnet' (HRNet-W32) backbone exists in the reference; got %r" % ns.backbone)
+    if ns.backbone not in ('hrnet', 'hrnetv4', 'resnet50'):
+        # the reference only ever builds HRNet-W32 (acr/model.py:27), whatever --backbone says (acr/config.py:95: "resnet50
+        # or hrnet", default 'hrnetv4'); 'resnet50' selects the build-defined ResNet-50 of BASELINE.json configs[1]
+        # (schema._resnet50_backbone) - there is no reference network or checkpoint behind it
+        raise ValueError("backbone %r: 'hrnet' (HRNet-W32, the reference's only network) or 'resnet50' (build-defined)" % ns.backbone)
     if 'part' not in ns.attention_mode:
         raise ValueError('attention_mode must contain "part" (acr/model.py:698-701)')
     if ns.prior_mode != 'cross' or not ns.inter_prior or ns.dataset == 'FreiHand':

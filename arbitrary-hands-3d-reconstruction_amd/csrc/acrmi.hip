@@ -207,6 +207,15 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
     }
     case ACRMI_OP_STEM: {
       const auto& d = desc(op.out_buf);
+      if (op.ksize == 7) {     // ResNet stem (stem7.hip)
+        if (d.dtype)
+          HIPCHK(c, launch_stem7_h16(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf),
+                                     d.cs, op.out_coff, op.relu, d.dtype, s));
+        else
+          HIPCHK(c, launch_stem7(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf), d.cs,
+                                 op.out_coff, op.relu, s));
+        return ACRMI_OK;
+      }
       if (d.dtype)
         HIPCHK(c, launch_stem_h16(img, B, 2 * d.h, 2 * d.w, c->weights + op.w_off, c->weights + op.b_off, ptr(op.out_buf),
                                   d.cs, op.out_coff, op.relu, d.dtype, s));
@@ -265,6 +274,16 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
                                         desc(op.out_buf).cs, op.out_coff, di.dtype, s));
       else
         HIPCHK(c, launch_bilinear2x(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
+                                    desc(op.out_buf).cs, op.out_coff, s));
+      return ACRMI_OK;
+    }
+    case ACRMI_OP_MAXPOOL: {
+      const auto& di = desc(op.in_buf);
+      if (di.dtype)
+        HIPCHK(c, launch_maxpool3s2_h16(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
+                                        desc(op.out_buf).cs, op.out_coff, di.dtype, s));
+      else
+        HIPCHK(c, launch_maxpool3s2(ptr(op.in_buf), B, di.h, di.w, di.cs, op.in_coff, op.cin, ptr(op.out_buf),
                                     desc(op.out_buf).cs, op.out_coff, s));
       return ACRMI_OK;
     }
@@ -337,7 +356,7 @@ static void op_rw(const acrmi_ctx* c, const acrmi_op& op, std::vector<int>& R, s
     case ACRMI_OP_U8NORM: case ACRMI_OP_STEM: w(op.out_buf); break;
     case ACRMI_OP_CONV: r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf); w(op.out_buf); break;
     case ACRMI_OP_FUSESUM: for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]); w(op.out_buf); break;
-    case ACRMI_OP_BILINEAR2X: r(op.in_buf); w(op.out_buf); break;
+    case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: r(op.in_buf); w(op.out_buf); break;
     case ACRMI_OP_POW11: r(op.out_buf); w(op.out_buf); break;
     case ACRMI_OP_ATTPOOL: r(op.in_buf); r(op.res_buf); w(op.out_buf); w(n_bufs); break;
     case ACRMI_OP_PAREBIAS: r(op.in_buf); w(op.out_buf); break;
@@ -484,7 +503,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
     bool need_in = false, need_out = true;
     switch (op.kind) {
       case ACRMI_OP_U8NORM: case ACRMI_OP_POW11: case ACRMI_OP_COORDFILL: case ACRMI_OP_STEM: break;
-      case ACRMI_OP_CONV: case ACRMI_OP_BILINEAR2X: case ACRMI_OP_ATTPOOL: case ACRMI_OP_PAREBIAS: case ACRMI_OP_POINTHEADS:
+      case ACRMI_OP_CONV: case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: case ACRMI_OP_ATTPOOL: case ACRMI_OP_PAREBIAS: case ACRMI_OP_POINTHEADS:
         need_in = true;
         break;
       case ACRMI_OP_FUSESUM: break;
@@ -496,7 +515,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
     if (op.kind == ACRMI_OP_CONV) {
       const int idt = bufs[op.in_buf].dtype, odt = bufs[op.out_buf].dtype;
       if (op.in_coff % (idt ? 8 : 4) || (op.ksize != 1 && op.ksize != 3) || op.stride < 1 || op.stride > 2 || op.cin <= 0 || op.cout <= 0 ||
-          op.groups <= 0 || (op.ksize == 1 && op.stride != 1))
+          op.groups <= 0)
         return fail(c, ACRMI_EINVAL, "op %d: unsupported conv geometry", i);
       const int algo = op.flags & 7;
       if (algo > 4) return fail(c, ACRMI_EINVAL, "op %d: unknown conv algo %d", i, algo);
@@ -550,9 +569,13 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
     if (op.kind == ACRMI_OP_STEM) {
       if (bufs[op.out_buf].dtype && (bufs[op.out_buf].cs % 8 || op.out_coff % 8))
         return fail(c, ACRMI_EINVAL, "op %d: a 16-bit stem output needs channel stride / offset in multiples of 8", i);
-      if (op.cout != 64 || !stem_shape_ok(2 * bufs[op.out_buf].h, 2 * bufs[op.out_buf].w, bufs[op.out_buf].cs, op.out_coff))
+      if (op.ksize != 3 && op.ksize != 7) return fail(c, ACRMI_EINVAL, "op %d: the stem kernels are 3x3 and 7x7 (stride 2)", i);
+      const bool ok = op.ksize == 7 ? stem7_shape_ok(2 * bufs[op.out_buf].h, 2 * bufs[op.out_buf].w, bufs[op.out_buf].cs, op.out_coff)
+                                    : stem_shape_ok(2 * bufs[op.out_buf].h, 2 * bufs[op.out_buf].w, bufs[op.out_buf].cs, op.out_coff);
+      if (op.cout != 64 || !ok)
         return fail(c, ACRMI_EINVAL, "op %d: the stem kernel needs 64 output channels and a map of 8x64-pixel strips", i);
-      if (!w_ok(op.w_off, 14 * 2 * 64) || !w_ok(op.b_off, 64)) return fail(c, ACRMI_EINVAL, "op %d: stem weights outside the blob", i);
+      if (!w_ok(op.w_off, (op.ksize == 7 ? 74 : 14) * 2 * 64) || !w_ok(op.b_off, 64))
+        return fail(c, ACRMI_EINVAL, "op %d: stem weights outside the blob", i);
     }
     if (op.kind == ACRMI_OP_FUSESUM) {
       const int vq = bufs[op.out_buf].dtype ? 8 : 4;      // elements per 16-byte vector
@@ -566,6 +589,13 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
             (bufs[op.term_buf[t]].w << op.term_shift[t]) != bufs[op.out_buf].w)
           return fail(c, ACRMI_EINVAL, "op %d: fuse-sum term %d does not fit the output", i, t);
       }
+    }
+    if (op.kind == ACRMI_OP_MAXPOOL) {
+      const int vq = bufs[op.in_buf].dtype ? 8 : 4;
+      if (op.cin <= 0 || bufs[op.in_buf].dtype != bufs[op.out_buf].dtype || op.cin % vq || op.in_coff % vq || op.out_coff % vq ||
+          op.in_coff + op.cin > bufs[op.in_buf].cs || op.out_coff + op.cin > bufs[op.out_buf].cs ||
+          bufs[op.out_buf].h != (bufs[op.in_buf].h - 1) / 2 + 1 || bufs[op.out_buf].w != (bufs[op.in_buf].w - 1) / 2 + 1)
+        return fail(c, ACRMI_EINVAL, "op %d: bad max-pool geometry", i);
     }
     if (op.kind == ACRMI_OP_BILINEAR2X &&
         (op.cin <= 0 || bufs[op.in_buf].dtype != bufs[op.out_buf].dtype || op.cin % (bufs[op.in_buf].dtype ? 8 : 4) ||
@@ -1019,8 +1049,8 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
                     out_coff % 4 || (res && (res_cs % 4 || res_coff % 4))))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 3 needs groups 1, Cin <= 32, Cout = 32, H %% 8 == 0, W %% 16 == 0");
   if (algo == 4 && cin <= 32) return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 4 needs Cin > 32");
-  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1))
-    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 s1/s2 and 1x1 s1 are implemented (got k%d s%d)", ksize, stride);
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 and 1x1 at stride 1 / 2 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: input channel stride/offset must be multiples of 4");
   if (in_coff < 0 || out_coff < 0 || res_coff < 0 || in_coff + groups * cin > in_cs || out_coff + groups * cout > out_cs ||
@@ -1090,8 +1120,8 @@ int acrmi_conv2d_h16(const void* in, int B, int H, int W, int in_cs, int in_coff
   if (!in || !w_packed || !bias || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || groups <= 0 ||
       (dtype != ACRMI_DT_F16 && dtype != ACRMI_DT_BF16))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: bad arguments");
-  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1) || (out_f32 && stride != 1))
-    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: 3x3 s1/s2 and 1x1 s1 (fp32 output: stride 1 only); got k%d s%d", ksize, stride);
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (out_f32 && stride != 1))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: 3x3 and 1x1 at stride 1 / 2 (fp32 output: stride 1 only); got k%d s%d", ksize, stride);
   const int oq = out_f32 ? 4 : 8;      // elements per 16-byte vector of the output / residual
   if (in_cs % 8 || in_coff % 8 || (groups > 1 && cin % 2) || out_cs % oq || (res && res_cs % oq))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: channel strides must be multiples of 16 bytes");

@@ -606,10 +606,20 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     if (n32 || (fine && tiles8 * nb2 < cus)) return launch_ws2<3, 2, 8, 16, 4, 1, 1, 1, 16, 2>(a, s);
     return launch_ws2<3, 2, 8, 16, 2, 2, 2, 1, 16, 2>(a, s);
   }
+  if (a.ks == 1 && a.stride == 2) {
+    // the projection shortcut of a strided ResNet block (torchvision resnet.py downsample: 1x1 stride 2): the loader stages
+    // the whole 15x31-pixel patch, the tap reads every other pixel of it
+    if (n32) return launch_ws2<1, 2, 8, 16, 4, 1, 1, 1, 32, 2>(a, s);
+    return launch_ws2<1, 2, 8, 16, 2, 2, 2, 1, 32, 2>(a, s);
+  }
   if (a.ks == 1 && a.stride == 1) {
     if (n32) return (small || (fine && tiles16 < cus)) ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s)
                                                         : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
-    if (fine && tiles8 * nb2 < cus) return launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s);
+    // (a short contraction writing many channels - layer1's 64 -> 256 + residual - is latency-bound on one or two
+    //  frames: 32-cout items keep four of them in flight per CU; 34 -> 24 us on one frame, 36 -> 27 on two, slower from
+    //  four frames on; conv_bench --cfg 808 forces it)
+    if ((fine && (tiles8 * nb2 < cus || (a.Cin <= 64 && tiles8 * nb2 <= 4 * cus))) || g_force_cfg == 808)
+      return launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s);
     return (small || (fine && tiles16 * nb2 < cus)) ? launch_ws2<1, 1, 8, 16, 2, 2, 2, 1, 64, 2>(a, s)
                                                     : launch_ws2<1, 1, 16, 16, 4, 2, 1, 2, 64, 4>(a, s);
   }

@@ -368,4 +368,85 @@ hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int
   return hipGetLastError();
 }
 
+// Max pooling 3x3, stride 2, padding 1 (ResNet stem, torchvision resnet.py maxpool; padded positions do not take part):
+// NHWC, 4 floats / 8 halfs per thread.  The maximum of values of the storage type is exact in every type.
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, int B, int H, int W, int in_cs, int in_coff,
+                                                         int C4, float* __restrict__ out, int out_cs, int out_coff) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long n = (long)B * Ho * Wo * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c4 = i % C4;
+    long p = i / C4;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const float* base = in + (size_t)b * H * W * in_cs + in_coff + c4 * 4;
+    f32x4 r = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y = 2 * oy + dy, x = 2 * ox + dx;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)y * W + x) * in_cs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], v[e]);
+      }
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_coff + c4 * 4) = r;
+  }
+}
+hipError_t launch_maxpool3s2(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out, int out_cs,
+                             int out_coff, hipStream_t s) {
+  const long n = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4);
+  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, in, B, H, W, in_cs, in_coff, C / 4, out,
+                     out_cs, out_coff);
+  return hipGetLastError();
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void maxpool3s2_h16_kernel(const unsigned short* __restrict__ in, int B, int H, int W, int in_cs,
+                                                             int in_coff, int C8, unsigned short* __restrict__ out, int out_cs,
+                                                             int out_coff) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long n = (long)B * Ho * Wo * C8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c8 = i % C8;
+    long p = i / C8;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const unsigned short* base = in + (size_t)b * H * W * in_cs + in_coff + c8 * 8;
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y = 2 * oy + dy, x = 2 * ox + dx;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        float v[8];
+        unpack8<BF>(*reinterpret_cast<const f32x4*>(base + ((size_t)y * W + x) * in_cs), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = fmaxf(r[e], v[e]);
+      }
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_coff + c8 * 8) = pack8<BF>(r);
+  }
+}
+hipError_t launch_maxpool3s2_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int C, void* out, int out_cs,
+                                 int out_coff, int dtype, hipStream_t s) {
+  const long n = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 8);
+  auto i16 = reinterpret_cast<const unsigned short*>(in);
+  auto o16 = reinterpret_cast<unsigned short*>(out);
+  if (dtype == 2)
+    hipLaunchKernelGGL(maxpool3s2_h16_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, i16, B, H, W, in_cs, in_coff, C / 8,
+                       o16, out_cs, out_coff);
+  else
+    hipLaunchKernelGGL(maxpool3s2_h16_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, i16, B, H, W, in_cs, in_coff, C / 8,
+                       o16, out_cs, out_coff);
+  return hipGetLastError();
+}
+
 }  // namespace acrmi

@@ -69,6 +69,12 @@ bool stem_shape_ok(int H, int W, int out_cs, int out_coff);
 hipError_t launch_stem(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, float* out,
                        int out_cs, int out_coff, int relu, hipStream_t s);
 // the same with the output rounded to f16 / bf16 (out_cs / out_coff in elements, multiples of 8)
+// ResNet stem (7x7 stride 2 pad 3, csrc/stem7.hip): wpk = packer.pack_stem7 fragments [74][2][64]
+bool stem7_shape_ok(int H, int W, int out_cs, int out_coff);
+hipError_t launch_stem7(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, float* out,
+                        int out_cs, int out_coff, int relu, hipStream_t s);
+hipError_t launch_stem7_h16(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, void* out,
+                            int out_cs, int out_coff, int relu, int dtype, hipStream_t s);
 hipError_t launch_stem_h16(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, void* out,
                            int out_cs, int out_coff, int relu, int dtype, hipStream_t s);
 hipError_t launch_bilinear2x(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out,
@@ -85,6 +91,10 @@ hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int
 hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s);
 hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, hipStream_t s);
 // 16-bit storage variants (dtype = ACRMI_DT_F16 / ACRMI_DT_BF16; strides and offsets in elements, C % 8 == 0)
+hipError_t launch_maxpool3s2(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out, int out_cs,
+                             int out_coff, hipStream_t s);
+hipError_t launch_maxpool3s2_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int C, void* out, int out_cs,
+                                 int out_coff, int dtype, hipStream_t s);
 hipError_t launch_bilinear2x_h16(const void* in, int B, int H, int W, int in_cs, int in_coff, int C, void* out, int out_cs,
                                  int out_coff, int dtype, hipStream_t s);
 hipError_t launch_fuse_sum_h16(const FuseArgs& a, int dtype, hipStream_t s);   // a.term / a.out carry 16-bit pointers

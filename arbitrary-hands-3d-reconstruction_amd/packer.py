@@ -10,7 +10,7 @@ activation buffers.  Pure numpy; runs on the host once per checkpoint.
 import numpy as np
 
 from . import _lib
-from .schema import stage_cfg, state_dict_schema, width_of
+from .schema import RESNET50, RESNET50_LAYERS, RESNET50_UP, backbone_channels, stage_cfg, state_dict_schema, width_of
 
 EPS = 1e-5
 # 3x3 stride-1 convolutions run as Winograd F(2,3) along x (exact-arithmetic equivalent, 1.5x fewer MFMAs;
@@ -136,6 +136,17 @@ def pack_stem(w, b):
     wk = np.zeros((64, 28))
     wk[:, :27] = np.asarray(w, np.float64).transpose(0, 2, 3, 1).reshape(64, 27)       # [cout][ky][kx][c]
     frag = wk.reshape(2, 32, 14, 2).transpose(2, 0, 3, 1)                               # [s][n][lh][li]
+    return np.ascontiguousarray(frag, np.float32).reshape(-1), np.asarray(b, np.float32).copy()
+
+
+def pack_stem7(w, b):
+    """ResNet conv1 filters [64, 3, 7, 7] (BN folded) -> the register-resident A fragments of stem7_kernel (csrc/stem7.hip):
+    [step s 74][n-tile 2][lane 64] with cout = 32*n + (lane & 31), k = 2*s + (lane >> 5), k = (ky*7 + kx)*3 + c
+    (k = 147 is the zero pad of the 148-wide reduction); bias [64]."""
+    assert w.shape == (64, 3, 7, 7)
+    wk = np.zeros((64, 148))
+    wk[:, :147] = np.asarray(w, np.float64).transpose(0, 2, 3, 1).reshape(64, 147)     # [cout][ky][kx][c]
+    frag = wk.reshape(2, 32, 74, 2).transpose(2, 0, 3, 1)                               # [s][n][lh][li]
     return np.ascontiguousarray(frag, np.float32).reshape(-1), np.asarray(b, np.float32).copy()
 
 
@@ -453,8 +464,9 @@ class Program(object):
         self.release(t, x)
         return y
 
-    def bottleneck(self, x, p, cat=None):
-        """acr/model.py:519-539.  cat: x is channels [0, Cin) of the 2 Cin-channel buffer `cat` (a block with a projection
+    def bottleneck(self, x, p, cat=None, stride=1):
+        """acr/model.py:519-539.  stride 2 (ResNet-50 only, torchvision's layout): on the 3x3 conv and on the 1x1
+        projection shortcut.  cat: x is channels [0, Cin) of the 2 Cin-channel buffer `cat` (a block with a projection
         shortcut): the 3x3 conv writes its output next to x and the block's last conv + projection become ONE 1x1
         convolution over the concatenated channels, y = relu([W_ds | W_3] [x ; t2] + b_ds + b_3) - the projected
         shortcut (Cout channels written, then read back as a residual: 2 x 1.07 GB at batch 64 for layer1.0) never
@@ -462,7 +474,7 @@ class Program(object):
         cin = self.sd[p + '.conv1.weight'].shape[1]
         t1 = self.conv_bn(x, p + '.conv1', p + '.bn1', 1, 1, True, cin=cin)
         if cat is not None:
-            assert cat == x and (p + '.downsample.0.weight') in self.sd
+            assert cat == x and stride == 1 and (p + '.downsample.0.weight') in self.sd
             mid = self.sd[p + '.conv2.weight'].shape[0]
             assert mid == cin and self.dims(cat)[2] >= 2 * cin
             self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, 1, True, out=cat, out_coff=cin)
@@ -471,10 +483,10 @@ class Program(object):
             y = self.conv(p + '.conv3+downsample', cat, [(np.concatenate([wd, w3], 1), bd + b3)], 1, 1, True)
             self.release(cat)
             return y
-        t2 = self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, 1, True)
+        t2 = self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, stride, True)
         self.release(t1)
         if (p + '.downsample.0.weight') in self.sd:
-            res = self.conv_bn(x, p + '.downsample.0', p + '.downsample.1', 1, 1, False)
+            res = self.conv_bn(x, p + '.downsample.0', p + '.downsample.1', 1, stride, False)
             self.release(x)
         else:
             res = x
@@ -573,13 +585,58 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
         check_state_dict(sd)
     if precision not in PRECISIONS:
         raise ValueError('precision %r: one of %s' % (precision, sorted(PRECISIONS)))
-    width = width_of({k: _np(v) for k, v in sd.items() if k == 'backbone.transition1.0.0.weight'})
-    STAGE_CFG = stage_cfg(width)
-    c0 = width
+    width = width_of({k: _np(v) for k, v in sd.items() if k in ('backbone.transition1.0.0.weight', 'backbone.layer4.0.conv1.weight')})
+    STAGE_CFG = None if width == RESNET50 else stage_cfg(width)
+    c0 = backbone_channels(width)
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
     P = Program(sd, dt, keep_weights, keep_all, wino24, splitk)
     b = 'backbone.'
+    taps = {}
+    x34 = None
+    if width == RESNET50:
+        # ---- ResNet-50 (BASELINE.json configs[1]; build-defined, schema._resnet50_backbone / oracle resnet50_backbone) ----
+        w, bb = P.folded(b + 'conv1', b + 'bn1')
+        x = P.buf(256, 256, 64)
+        wp, bp = pack_stem7(w, bb)
+        P._op(b + 'conv1', 2.0 * 256 * 256 * 64 * 3 * 49, kind=_lib.OP_STEM, out_buf=x, cin=3, cout=64, ksize=7, stride=2,
+              relu=1, groups=1, w_off=P.blob.add(wp), b_off=P.blob.add(bp))
+        P.op_info[-1]['algo'] = 'stem7_u8'
+        if keep_weights:
+            P.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(bb, np.float64))]
+        if keep_taps:
+            taps['stem'] = P.pin(x)
+        # layer1.0 has a stride-1 projection shortcut: the pooled map goes into channels 0..63 of a 128-channel buffer and
+        # the block takes conv3 + downsample as one convolution (Program.bottleneck cat=)
+        cat = P.buf(128, 128, 128) if FUSE_PROJECTION else None
+        pooled = cat if cat is not None else P.buf(128, 128, 64)
+        P._op(b + 'maxpool', 0.0, kind=_lib.OP_MAXPOOL, in_buf=x, out_buf=pooled, cin=64)
+        P.release(x)
+        x = pooled
+        for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+            for i in range(blocks):
+                x = P.bottleneck(x, b + 'layer%d.%d' % (li + 1, i), cat=cat if (li == 0 and i == 0) else None,
+                                 stride=stride if i == 0 else 1)
+        if keep_taps:
+            taps['layer4'] = P.pin(x)
+        x34 = P.buf(128, 128, c0 + 2, persistent=True)      # backbone output (64) + coord maps (2), acr/model.py:52
+        P._op('coordfill', 0.0, kind=_lib.OP_COORDFILL, out_buf=x34, out_coff=c0)
+        for k, c in enumerate(RESNET50_UP):
+            h, w_, cs = P.dims(x)
+            cin = P.sd[b + 'deconv_layers.%d.0.weight' % k].shape[1]
+            up = P.buf(2 * h, 2 * w_, cin)
+            P._op(b + 'deconv_layers.%d.bilinear2x' % k, 0.0, kind=_lib.OP_BILINEAR2X, in_buf=x, out_buf=up, cin=cin)
+            P.release(x)
+            x = P.conv_bn(up, b + 'deconv_layers.%d.0' % k, b + 'deconv_layers.%d.1' % k, 3, 1, True,
+                          out=x34 if k == len(RESNET50_UP) - 1 else None)
+            P.release(up)
+    else:
+        x34 = _lower_hrnet(P, sd, b, STAGE_CFG, c0, keep_taps, keep_weights, taps)
+    return _lower_heads(P, sd, b, x34, c0, dt, point_heads, precision, width, taps)
+
+
+def _lower_hrnet(P, sd, b, STAGE_CFG, c0, keep_taps, keep_weights, taps):
+    """acr/model.py:785-865: stem, layer1, transitions, 8 HR modules -> the persistent [128,128,c0 + 2] map"""
     # ---- stem -----------------------------------------------------------------------------------
     w, bb = P.folded(b + 'conv1', b + 'bn1')
     if STEM_FUSED:
@@ -602,7 +659,6 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True, out=cat)
     P.release(x)
     x = x1
-    taps = {}
     if keep_taps:
         taps['stem'] = P.pin(x)
     for i in range(4):
@@ -628,6 +684,12 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
                              final_out=x34 if last else None)
         if keep_taps and s < 4:
             taps['stage%d' % s] = P.pin(xs[0])
+    return x34
+
+
+def _lower_heads(P, sd, b, x34, c0, dt, point_heads, precision, width, taps):
+    """acr/model.py:47-166, 374-463: segmentation head, the eight towers, the part branch - on any backbone's
+    [128,128,c0 + 2] map"""
     # ---- part-segmentation head (acr/model.py:374-463) ------------------------------------------
     u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
     g = b + 'hand_segm.segm_head.segm_net.double_conv'

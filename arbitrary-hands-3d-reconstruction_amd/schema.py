@@ -59,18 +59,58 @@ def fuse_plan(nb, multi_scale):
     return [(i, j) for i in range(nb if multi_scale else 1) for j in range(nb) if j != i]
 
 
+RESNET50 = 'resnet50'     # the `width` of a ResNet-50 checkpoint (BASELINE.json configs[1]'s backbone; build-defined)
+RESNET50_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))      # (planes, blocks, stride): torchvision resnet50
+RESNET50_UP = (256, 128, 64)                                               # channels of the three x2 upsampling stages
+
+
+def backbone_channels(width):
+    """channels of the 128x128 backbone output the heads read (before the 2 coordinate channels)"""
+    return RESNET50_UP[-1] if width == RESNET50 else int(width)
+
+
 def width_of(sd):
-    """HRNet width of a checkpoint (bare keys): the channel count of branch 0."""
+    """Backbone of a checkpoint (bare keys): HRNet width (channel count of branch 0: 32 / 48) or 'resnet50'."""
+    if 'backbone.layer4.0.conv1.weight' in sd:
+        return RESNET50
     w = sd.get('backbone.transition1.0.0.weight')
     return 32 if w is None else int(w.shape[0])
 
 
+def _resnet50_backbone(d):
+    """ResNet-50 trunk in torchvision's layout and key names (conv1 7x7 stride 2, max-pool, Bottleneck x [3,4,6,3] with
+    the stride on the 3x3 conv and a 1x1 strided projection shortcut in the first block of every layer) + three
+    upsampling stages `deconv_layers.{k}` = bilinear x2 (align_corners) -> conv3x3 -> BN -> ReLU (256, 128, 64 channels)
+    that bring the 16x16x2048 map back to the 128x128 resolution the ACR heads work at.  BUILD-DEFINED: the reference
+    has no ResNet (`--backbone resnet50` is a dead flag, acr/config.py:95); BASELINE.json configs[1] names the
+    backbone, this is the definition it is measured on."""
+    b = 'backbone.'
+    _conv(d, b + 'conv1', 64, 3, 7, False); _bn(d, b + 'bn1', 64)
+    cin = 64
+    for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+        for i in range(blocks):
+            p = b + 'layer%d.%d' % (li + 1, i)
+            _conv(d, p + '.conv1', planes, cin, 1, False); _bn(d, p + '.bn1', planes)
+            _conv(d, p + '.conv2', planes, planes, 3, False); _bn(d, p + '.bn2', planes)
+            _conv(d, p + '.conv3', 4 * planes, planes, 1, False); _bn(d, p + '.bn3', 4 * planes)
+            if i == 0:
+                _conv(d, p + '.downsample.0', 4 * planes, cin, 1, False); _bn(d, p + '.downsample.1', 4 * planes)
+            cin = 4 * planes
+    for k, c in enumerate(RESNET50_UP):
+        _conv(d, b + 'deconv_layers.%d.0' % k, c, cin, 3, False); _bn(d, b + 'deconv_layers.%d.1' % k, c)
+        cin = c
+
+
 def state_dict_schema(width=32):
-    """OrderedDict key -> shape, in the reference's registration order."""
-    STAGE_CFG = stage_cfg(width)
-    c0 = STAGE_CFG[2]['channels'][0]
+    """OrderedDict key -> shape, in the reference's registration order.  width: 32 (the reference) / 48 / 'resnet50'."""
     d = OrderedDict()
     b = 'backbone.'
+    if width == RESNET50:
+        _resnet50_backbone(d)
+        _heads(d, backbone_channels(width))
+        return d
+    STAGE_CFG = stage_cfg(width)
+    c0 = STAGE_CFG[2]['channels'][0]
     _conv(d, b + 'conv1', 64, 3, 3, False); _bn(d, b + 'bn1', 64)
     _conv(d, b + 'conv2', 64, 64, 3, False); _bn(d, b + 'bn2', 64)
     # layer1: 4 Bottlenecks, planes 64, expansion 4
@@ -115,6 +155,12 @@ def state_dict_schema(width=32):
                             _conv(d, f + '.%d.0' % k, cout, ch[j], 3, False)
                             _bn(d, f + '.%d.1' % k, cout)
         pre = ch
+    _heads(d, c0)
+    return d
+
+
+def _heads(d, c0):
+    b = 'backbone.'
     # part-segmentation head (acr/model.py:374-463)
     u = b + 'hand_segm.segm_head.upsampler.up1.conv.double_conv'
     _conv(d, u + '.0', 16, c0, 3, True); _bn(d, u + '.1', 16)

@@ -22,7 +22,8 @@ def make_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefix='', wi
 
     center_bias: (left, right) bias of the 64->1 center-tower exit conv; use a
     large negative value to suppress detections of that hand.
-    width: HRNet width (32 = the reference's network; 48 = BASELINE.json configs[4], schema.stage_cfg).
+    width: HRNet width (32 = the reference's network; 48 = BASELINE.json configs[4], schema.stage_cfg) or 'resnet50'
+    (BASELINE.json configs[1]'s backbone as schema._resnet50_backbone defines it).
     law: 'benign' (above) or 'hostile' (make_hostile_state_dict: trained-like BatchNorm statistics).
     """
     if law == 'hostile':
@@ -93,6 +94,8 @@ def make_hostile_state_dict(seed=0, center_bias=(0.3, 0.3), as_torch=True, prefi
         every conv that reads it has its weights /= stream_scale: activations of O(stream_scale) (up to ~1e2) wherever
         the fp32 path adds residuals, fuses branches or feeds a head.
     The re-parametrisation is done in float64 and rounded once to float32."""
+    if not isinstance(width, int):
+        raise ValueError('the hostile re-parametrisation is written for the HRNet topologies')
     sd = make_state_dict(seed, center_bias, as_torch=False, prefix='', width=width)
     sch = state_dict_schema(width)
     c0 = width

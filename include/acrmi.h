@@ -67,9 +67,12 @@ enum {
                              map, aux = per-frame bias; w_off = 3 packed towers, w_off2 = mix weights);
                              acr/model.py:71-99,160-164 restricted to the pixels acr/result_parser.py:49-57,
                              141-145 samples */
+  ACRMI_OP_MAXPOOL = 11,  /* max pooling 3x3 stride 2 pad 1 of cin channels (ResNet stem; in -> out [B,(H-1)/2+1,(W-1)/2+1]) */
   ACRMI_OP_STEM = 10      /* uint8 image -> relu(conv3x3 stride 2 (x/255*2-1) + b), 3 -> 64 channels: U8NORM + the
                              first CONV in one kernel (acr/model.py:832,589-603; in = the image, out = [B,H/2,W/2,>=64]);
-                             w_off = packer.pack_stem fragments [14][2][64], b_off = 64 biases */
+                             w_off = packer.pack_stem fragments [14][2][64], b_off = 64 biases.  ksize = 7: the ResNet stem
+                             (7x7 stride 2 pad 3; BASELINE.json configs[1]'s backbone), w_off = packer.pack_stem7
+                             fragments [74][2][64] */
 };
 
 /* acrmi_op.flags of a CONV, bit 3: a position-bias map - [Ho][Wo][round4(groups*Cout)] fp32 at blob offset w_off2 -

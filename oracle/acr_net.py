@@ -29,14 +29,15 @@ def basic_block(sd, x, p):
     return F.relu(out + x)
 
 
-def bottleneck(sd, x, p):
-    """acr/model.py:519-539"""
+def bottleneck(sd, x, p, stride=1):
+    """acr/model.py:519-539 (stride 1).  stride 2: the first block of a ResNet-50 layer, torchvision's layout - stride on
+    the 3x3 conv and on the 1x1 projection shortcut (resnet50_backbone; not part of the reference)."""
     out = F.relu(_bn(sd, _conv(sd, x, p + '.conv1', 1, 0), p + '.bn1'))
-    out = F.relu(_bn(sd, _conv(sd, out, p + '.conv2'), p + '.bn2'))
+    out = F.relu(_bn(sd, _conv(sd, out, p + '.conv2', stride, 1), p + '.bn2'))
     out = _bn(sd, _conv(sd, out, p + '.conv3', 1, 0), p + '.bn3')
     res = x
     if (p + '.downsample.0.weight') in sd:
-        res = _bn(sd, _conv(sd, x, p + '.downsample.0', 1, 0), p + '.downsample.1')
+        res = _bn(sd, _conv(sd, x, p + '.downsample.0', stride, 0), p + '.downsample.1')
     return F.relu(out + res)
 
 
@@ -68,8 +69,37 @@ def hr_module(sd, xs, p, multi_scale=True):
     return outs
 
 
+RESNET50_LAYERS = ((3, 1), (4, 2), (6, 2), (3, 2))      # (blocks, stride of the first block): torchvision resnet50
+
+
+def resnet50_backbone(sd, image_u8, taps=None):
+    """NO REFERENCE COUNTERPART (the reference's `--backbone resnet50` is a dead flag, acr/config.py:95): the backbone
+    BASELINE.json configs[1] names, as the build defines it (schema._resnet50_backbone) - torchvision's ResNet-50 forward
+    (conv1 7x7 stride 2 pad 3 -> BN -> ReLU -> max-pool 3x3 stride 2 pad 1 -> Bottlenecks [3,4,6,3]) followed by three
+    stages of bilinear x2 (align_corners=True) -> conv3x3 -> BN -> ReLU down to 64 channels at 128x128.  Own-oracle of
+    the HIP path for that configuration; the normalisation and the heads are the reference's."""
+    b = 'backbone.'
+    x = ((image_u8.permute(0, 3, 1, 2).float() / 255.) * 2.0 - 1.0).contiguous()
+    x = F.relu(_bn(sd, _conv(sd, x, b + 'conv1', 2, 3), b + 'bn1'))
+    if taps is not None:
+        taps['stem'] = x
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (blocks, stride) in enumerate(RESNET50_LAYERS):
+        for i in range(blocks):
+            x = bottleneck(sd, x, b + 'layer%d.%d' % (li + 1, i), stride if i == 0 else 1)
+        if taps is not None:
+            taps['layer%d' % (li + 1)] = x
+    for k in range(3):
+        x = F.interpolate(x, scale_factor=(2, 2), mode='bilinear', align_corners=True)
+        x = F.relu(_bn(sd, _conv(sd, x, b + 'deconv_layers.%d.0' % k), b + 'deconv_layers.%d.1' % k))
+    return x
+
+
 def backbone(sd, image_u8, taps=None):
-    """acr/model.py:831-865.  image_u8: [B,512,512,3] uint8/float RGB (NHWC)."""
+    """acr/model.py:831-865.  image_u8: [B,512,512,3] uint8/float RGB (NHWC).  (A checkpoint with ResNet-50 keys goes
+    to resnet50_backbone.)"""
+    if 'backbone.layer4.0.conv1.weight' in sd:
+        return resnet50_backbone(sd, image_u8, taps)
     b = 'backbone.'
     x = ((image_u8.permute(0, 3, 1, 2).float() / 255.) * 2.0 - 1.0).contiguous()
     x = F.relu(_bn(sd, _conv(sd, x, b + 'conv1', 2, 1), b + 'bn1'))

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
+OP_MAXPOOL = 11
 MODE_POINT = 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV (include/acrmi.h)
 CONV_SPLITK = 16
@@ -85,7 +86,7 @@ class Interp(object):
         (w, b), = info['wb']
         x = (img.to(torch.float32) / 255.0) * 2.0 - 1.0                     # stem_kernel's table expression
         w = torch.from_numpy(np.asarray(w, np.float32)).to(torch.float64)   # pack_stem keeps fp32 filters
-        y = F.conv2d(x.permute(0, 3, 1, 2).to(torch.float64), w, None, 2, 1).permute(0, 2, 3, 1)
+        y = F.conv2d(x.permute(0, 3, 1, 2).to(torch.float64), w, None, 2, op.ksize // 2).permute(0, 2, 3, 1)   # 3x3 / 7x7 (ResNet)
         y = (y + torch.from_numpy(np.asarray(b, np.float32)).to(torch.float64)).to(torch.float32)
         if op.relu:
             y = torch.relu(y)
@@ -123,6 +124,11 @@ class Interp(object):
         hy_, ly_ = hy[None, :, None, None], ly[None, :, None, None]
         r = hy_ * (hx_ * v00 + lx_ * v01) + ly_ * (hx_ * v10 + lx_ * v11)
         self.bufs[op.out_buf][..., op.out_coff:op.out_coff + op.cin] = rnd(r, self.dts[op.out_buf])
+
+    def maxpool(self, op):
+        x = self.bufs[op.in_buf][..., op.in_coff:op.in_coff + op.cin]
+        y = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)      # exact in every storage type
+        self.bufs[op.out_buf][..., op.out_coff:op.out_coff + op.cin] = y
 
     def pow11(self, op):
         b = self.bufs[op.out_buf]
@@ -177,6 +183,8 @@ class Interp(object):
                 self.fuse_sum(op)
             elif k == OP_BILINEAR2X:
                 self.bilinear2x(op)
+            elif k == OP_MAXPOOL:
+                self.maxpool(op)
             elif k == OP_POW11:
                 self.pow11(op)
             elif k == OP_COORDFILL:
