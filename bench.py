@@ -187,6 +187,46 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
     return res
 
 
+def other_configs(tables, steps, warmup, local_rank):
+    """The per-GPU workloads of the BASELINE.json configs the headline does not cover, each on its own synthetic checkpoint,
+    two contexts in turn like the headline: configs[1] (batch 32, ResNet-50, bf16) and configs[4] (batch 64 per GPU,
+    HRNet-W48, fp16 program, fp16 MANO LBS).  Neither network exists in the reference (its only backbone is HRNet-W32 and
+    `--backbone resnet50` is a dead flag, acr/config.py:95): both are build-defined (schema.py) and checked against the
+    build's own oracle (tests/test_gpu_h16.py), which `parity` here says instead of quoting a number."""
+    synth = pkg('synth')
+    res = {}
+    for name, width, prec, B, mano16 in (('configs[1] resnet50 bf16 batch32', 'resnet50', 'bf16', 32, False),
+                                          ('configs[4] hrnet_w48 fp16 batch64 fp16-mano', 48, 'fp16', 64, True)):
+        sd = synth.make_state_dict(seed=0, width=width)
+        frames = torch.from_numpy(synth.make_frames(B, seed=0, structured=False)).cuda()
+        pool = pkg('engine').EnginePool(local_rank, n=2)
+        pool.load_state_dict(sd, max_batch=B, lanes=1, precision=prec)
+        pool.load_mano(tables)
+        pool.configure(lambda e: e.set_mano_fp16(mano16))
+        vsets = [pkg('parallel').alloc_result(B, pool.device)[1] for _ in range(2)]
+
+        def run(n):
+            pend = []
+            for i in range(n):
+                pend.append(pool.submit(frames, out=vsets[i % 2]))
+                while len(pend) > 1:
+                    pool.collect(pend.pop(0))
+            for t in pend:
+                pool.collect(t)
+        run(max(1, warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gflop = sum(i['flops'] for i in pool.engines[0].program['op_info'] if i.get('mode', 0) != pkg('_lib').MODE_POINT) / 1e9
+        res[name] = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+                     'gflop_per_frame': round(gflop, 1), 'tflops': round(B * steps * gflop / dt / 1e3, 1),
+                     'parity': 'no reference network: HIP vs the build\'s own oracle in tests/test_gpu_h16.py'}
+        pool.close()
+    return res
+
+
 def live_pmc(batch, timeout_s=300, precision='fp32'):
     """the PMC figures of the bench line measured in THIS run instead of read from profiles/ - bench.py
     re-executes itself (one warm-up + one step, one context, one stream) under `rocprofv3 --kernel-trace --pmc ...`, in
@@ -560,6 +600,7 @@ def main():
                 pool.close(keep_first=True)
                 pool = None
             out['reduced_precision'] = reduced_precision(sd, tables, frames, B, args.steps, args.warmup, oracle, local_rank)
+            out['other_configs'] = other_configs(tables, args.steps, args.warmup, local_rank)
         line = json.dumps(out)
     else:
         line = None

@@ -23,11 +23,12 @@ def main():
     ap.add_argument('--top', type=int, default=30)
     ap.add_argument('--json', default='')
     ap.add_argument('--precision', default='fp32', help='fp32 | fp16 | bf16')
-    ap.add_argument('--width', type=int, default=32, help='HRNet width (32 | 48)')
+    ap.add_argument('--width', default='32', help="HRNet width (32 | 48) or 'resnet50'")
     args = ap.parse_args()
     synth = pkg('synth')
     eng = pkg('engine').Engine(0)
-    eng.load_state_dict(synth.make_state_dict(seed=0, width=args.width), max_batch=args.batch, precision=args.precision)
+    width = args.width if args.width == 'resnet50' else int(args.width)
+    eng.load_state_dict(synth.make_state_dict(seed=0, width=width), max_batch=args.batch, precision=args.precision)
     eng.load_mano(synth.make_mano_tables(seed=1))
     x = torch.from_numpy(synth.make_frames(args.batch, seed=0, structured=True)).cuda()
     eng.profile_ops(x)
