@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ACRMI_LIB') or os.path.join(HERE, 'libacrmi.so')   # ACRMI_LIB: kernel experiments
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
-OP_MAXPOOL = 11
+OP_MAXPOOL, OP_PAIR1X1 = 11, 12
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV / acrmi_conv2d's algo: ACRMI_CONV_BIAS_MAP
 CONV_SPLITK = 16       # acrmi_op.flags of a CONV: ACRMI_CONV_SPLITK

@@ -277,6 +277,13 @@ static int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, h
                                     desc(op.out_buf).cs, op.out_coff, s));
       return ACRMI_OK;
     }
+    case ACRMI_OP_PAIR1X1: {
+      const auto& di = desc(op.in_buf);
+      HIPCHK(c, launch_pair1x1(ptr(op.in_buf), di.cs, op.in_coff, ptr(op.res_buf), desc(op.res_buf).cs, op.res_coff, ptr(op.out_buf),
+                               desc(op.out_buf).cs, op.out_coff, ptr(op.aux_buf), desc(op.aux_buf).cs, 0, c->weights + op.w_off,
+                               (long)B * di.h * di.w, s));
+      return ACRMI_OK;
+    }
     case ACRMI_OP_MAXPOOL: {
       const auto& di = desc(op.in_buf);
       if (di.dtype)
@@ -357,6 +364,7 @@ static void op_rw(const acrmi_ctx* c, const acrmi_op& op, std::vector<int>& R, s
     case ACRMI_OP_CONV: r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf); w(op.out_buf); break;
     case ACRMI_OP_FUSESUM: for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]); w(op.out_buf); break;
     case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: r(op.in_buf); w(op.out_buf); break;
+    case ACRMI_OP_PAIR1X1: r(op.in_buf); r(op.res_buf); w(op.out_buf); w(op.aux_buf); break;
     case ACRMI_OP_POW11: r(op.out_buf); w(op.out_buf); break;
     case ACRMI_OP_ATTPOOL: r(op.in_buf); r(op.res_buf); w(op.out_buf); w(n_bufs); break;
     case ACRMI_OP_PAREBIAS: r(op.in_buf); w(op.out_buf); break;
@@ -503,7 +511,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
     bool need_in = false, need_out = true;
     switch (op.kind) {
       case ACRMI_OP_U8NORM: case ACRMI_OP_POW11: case ACRMI_OP_COORDFILL: case ACRMI_OP_STEM: break;
-      case ACRMI_OP_CONV: case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: case ACRMI_OP_ATTPOOL: case ACRMI_OP_PAREBIAS: case ACRMI_OP_POINTHEADS:
+      case ACRMI_OP_CONV: case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: case ACRMI_OP_PAIR1X1: case ACRMI_OP_ATTPOOL: case ACRMI_OP_PAREBIAS: case ACRMI_OP_POINTHEADS:
         need_in = true;
         break;
       case ACRMI_OP_FUSESUM: break;
@@ -589,6 +597,19 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
             (bufs[op.term_buf[t]].w << op.term_shift[t]) != bufs[op.out_buf].w)
           return fail(c, ACRMI_EINVAL, "op %d: fuse-sum term %d does not fit the output", i, t);
       }
+    }
+    if (op.kind == ACRMI_OP_PAIR1X1) {
+      if (!buf_ok(op.res_buf) || !buf_ok(op.aux_buf) || op.cin != 64 || op.cout != 256)
+        return fail(c, ACRMI_EINVAL, "op %d: the 1x1 pair is 64 -> 256 (+ residual) -> 64 with in, res, out and aux buffers", i);
+      const int ids4[4] = {op.in_buf, op.res_buf, op.out_buf, op.aux_buf};
+      for (int id : ids4)
+        if (bufs[id].dtype != ACRMI_DT_F32 || bufs[id].h != bufs[op.in_buf].h || bufs[id].w != bufs[op.in_buf].w)
+          return fail(c, ACRMI_EINVAL, "op %d: the 1x1 pair's buffers must be fp32 maps of one size", i);
+      if (op.in_coff % 4 || op.res_coff % 4 || op.out_coff % 4 || op.in_coff + 64 > bufs[op.in_buf].cs ||
+          op.res_coff + 256 > bufs[op.res_buf].cs || op.out_coff + 256 > bufs[op.out_buf].cs || bufs[op.aux_buf].cs < 64 ||
+          op.out_buf == op.in_buf || op.aux_buf == op.in_buf || op.aux_buf == op.out_buf || op.aux_buf == op.res_buf)
+        return fail(c, ACRMI_EINVAL, "op %d: the 1x1 pair's channel slices do not fit / its buffers alias", i);
+      if (!w_ok(op.w_off, PAIR1X1_FLOATS)) return fail(c, ACRMI_EINVAL, "op %d: pair weights outside the blob", i);
     }
     if (op.kind == ACRMI_OP_MAXPOOL) {
       const int vq = bufs[op.in_buf].dtype ? 8 : 4;

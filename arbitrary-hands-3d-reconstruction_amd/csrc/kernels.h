@@ -69,6 +69,11 @@ bool stem_shape_ok(int H, int W, int out_cs, int out_coff);
 hipError_t launch_stem(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, float* out,
                        int out_cs, int out_coff, int relu, hipStream_t s);
 // the same with the output rounded to f16 / bf16 (out_cs / out_coff in elements, multiples of 8)
+// layer1's conv3 (64 -> 256, + residual, ReLU) chained with the next block's conv1 (256 -> 64, ReLU) in one kernel
+// (csrc/pair1x1.hip); wpk = packer.pack_pair1x1 (33088 floats); npix = B * H * W
+hipError_t launch_pair1x1(const float* t2, int t2_cs, int t2_coff, const float* x, int x_cs, int x_coff, float* y, int y_cs,
+                          int y_coff, float* t, int t_cs, int t_coff, const float* wpk, long npix, hipStream_t s);
+constexpr long PAIR1X1_FLOATS = 256 * 64 + 64 * 256 + 256 + 64;
 // ResNet stem (7x7 stride 2 pad 3, csrc/stem7.hip): wpk = packer.pack_stem7 fragments [74][2][64]
 bool stem7_shape_ok(int H, int W, int out_cs, int out_coff);
 hipError_t launch_stem7(const uint8_t* img, int B, int H, int W, const float* wpk, const float* bias, float* out,

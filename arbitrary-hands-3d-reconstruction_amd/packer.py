@@ -150,6 +150,30 @@ def pack_stem7(w, b):
     return np.ascontiguousarray(frag, np.float32).reshape(-1), np.asarray(b, np.float32).copy()
 
 
+def pack_pair1x1(w3, b3, w1, b1):
+    """Folded conv3 [256,64] / bias [256] of a layer1 Bottleneck and conv1 [64,256] / bias [64] of the NEXT one -> the LDS
+    image of pair1x1_kernel (csrc/pair1x1.hip), 33088 floats:
+      A1 [c 8][s4 8][lane 64][4]: W3[32 c + m][32 h + 4 s4 + e]           lane = 32 h + m   (k order of the first GEMM:
+                                                                           lane half h reads t2 channels 32 h ..)
+      A2 [c 8][nt 2][g 4][lane 64][4]: W1[32 nt + m][32 c + 8 g + 4 h + e]   (k order of the second GEMM = the row
+                                                                           order of the first one's accumulator registers)
+      b3 [c 8][g 4][h 2][4], b1 [nt 2][g 4][h 2][4]: biases in accumulator-register order."""
+    w3 = np.asarray(w3, np.float64).reshape(256, 64)
+    w1 = np.asarray(w1, np.float64).reshape(64, 256)
+    a1 = w3.reshape(8, 32, 2, 8, 4).transpose(0, 3, 2, 1, 4).reshape(-1)            # c, m, h, s4, e -> c, s4, h, m, e
+    a2 = w1.reshape(2, 32, 8, 4, 2, 4).transpose(2, 0, 3, 4, 1, 5).reshape(-1)      # nt, m, c, g, h, e -> c, nt, g, h, m, e
+    out = np.concatenate([a1, a2, np.asarray(b3, np.float64).reshape(-1), np.asarray(b1, np.float64).reshape(-1)])
+    assert out.size == 256 * 64 + 64 * 256 + 256 + 64
+    return out.astype(np.float32)
+
+
+# layer1's conv3 (64 -> 256 + residual + ReLU) and the next block's conv1 (256 -> 64 + ReLU) as ONE launch (OP_PAIR1X1): the
+# 256-channel map is written once and not read back by the pair (two HBM-bound launches otherwise).  Large-batch fp32
+# programs (Engine.load_state_dict: max_batch >= 16); with it layer1.0 keeps its projection shortcut as a separate conv (the
+# pair takes it as the residual).
+FUSE_PAIRS = True
+
+
 # the stem (u8norm + conv1) as one kernel reading the uint8 image; False = the two generic ops of round 1
 STEM_FUSED = True
 
@@ -292,11 +316,12 @@ class Blob(object):
 class Program(object):
     """Op list + buffer table under construction."""
 
-    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None, splitk=False):
+    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None, splitk=False, pairs=False):
         self.sd = {k: _np(v) for k, v in sd.items()}
         self.dt = dt             # storage type of the activations between layers (DT_*); head outputs stay fp32
         self.keep_weights = keep_weights
         self.splitk = splitk      # small-batch program: split-K lowering of the low-resolution 3x3 layers
+        self.pairs = pairs and dt == DT_F32      # large-batch fp32 program: layer1's conv3 / next conv1 pairs as one op
         self.wino24 = wino24      # None = packer.WINOGRAD_24
         self.keep_all = keep_all  # no lifetime-based buffer reuse: every intermediate map survives the run (tests)
         self.blob = Blob()
@@ -494,6 +519,47 @@ class Program(object):
         self.release(t2, res)
         return y
 
+    def bottleneck_chain(self, x, prefix, n, cat=None):
+        """n stride-1 Bottlenecks `prefix.{i}` in a row (HRNet's layer1, acr/model.py:738-752; ResNet-50's layer1).  With
+        self.pairs and 64 -> 256 -> 64 shapes, block i's conv3 (+ residual, ReLU) and block i + 1's conv1 (+ ReLU) are one
+        OP_PAIR1X1 launch; otherwise bottleneck() per block (cat: see there)."""
+        shapes_ok = all(self.sd['%s.%d.conv3.weight' % (prefix, i)].shape[:2] == (256, 64) and
+                        self.sd['%s.%d.conv1.weight' % (prefix, i)].shape[0] == 64 for i in range(n))
+        if not (self.pairs and shapes_ok and n >= 2):
+            for i in range(n):
+                x = self.bottleneck(x, '%s.%d' % (prefix, i), cat=cat if i == 0 else None)
+            return x
+        t1 = None
+        for i in range(n):
+            p = '%s.%d' % (prefix, i)
+            if t1 is None:
+                t1 = self.conv_bn(x, p + '.conv1', p + '.bn1', 1, 1, True, cin=self.sd[p + '.conv1.weight'].shape[1])
+            t2 = self.conv_bn(t1, p + '.conv2', p + '.bn2', 3, 1, True)
+            self.release(t1)
+            if (p + '.downsample.0.weight') in self.sd:
+                res = self.conv_bn(x, p + '.downsample.0', p + '.downsample.1', 1, 1, False,
+                                   cin=self.sd[p + '.downsample.0.weight'].shape[1])
+                self.release(x)
+            else:
+                res = x
+            if i == n - 1:
+                y = self.conv_bn(t2, p + '.conv3', p + '.bn3', 1, 1, True, res=res)
+                self.release(t2, res)
+                return y
+            q = '%s.%d' % (prefix, i + 1)
+            (w3, b3), (w1, b1) = self.folded(p + '.conv3', p + '.bn3'), self.folded(q + '.conv1', q + '.bn1')
+            h, w_, _ = self.dims(t2)
+            y, t1 = self.buf(h, w_, 256), self.buf(h, w_, 64)
+            self._op(p + '.conv3+' + q + '.conv1', 2.0 * h * w_ * (256 * 64 + 64 * 256), kind=_lib.OP_PAIR1X1, in_buf=t2, res_buf=res,
+                     out_buf=y, aux_buf=t1, cin=64, cout=256, ksize=1, stride=1, relu=1, groups=1,
+                     w_off=self.blob.add(pack_pair1x1(w3[:, :, 0, 0], b3, w1[:, :, 0, 0], b1)))
+            self.op_info[-1]['algo'] = 'pair1x1'
+            if self.keep_weights:
+                self.op_info[-1]['wb'] = [(np.asarray(w3, np.float64), np.asarray(b3, np.float64)),
+                                          (np.asarray(w1, np.float64), np.asarray(b1, np.float64))]
+            self.release(t2, res)
+            x = y
+
     def hr_module(self, xs, p, ch, multi_scale=True, final_out=None):
         """acr/model.py:668-686.  xs consumed; returns the fused outputs."""
         nb = len(xs)
@@ -561,7 +627,7 @@ def point_tower(P, side, k):
 
 
 def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', keep_weights=False, keep_all=False,
-          wino24=None, splitk=False):
+          wino24=None, splitk=False, pairs=None):
     """state dict -> dict(blob, bufs, ops, heads, op_info, taps, precision, width).  See module docstring.
     point_heads: also emit the MODE_POINT variant of the head program (ops tagged MODE_DENSE / MODE_POINT; fp32 W32 only).
     keep_taps: pin the buffers of the backbone taps the golden vectors hold (stem / layer1 / stage2 / stage3 branch 0,
@@ -576,6 +642,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     keep_weights: op_info[i]['wb'] keeps the folded fp64 filters of every conv (oracle/program.py, tests only).
     wino24: None = packer.WINOGRAD_24 (on); False lowers the 3x3 stride-1 layers with Cin > 32 to F(2x2,3x3) - what
     Engine.load_state_dict asks for when max_batch < 16 (single-frame / small-batch latency: batch 1 3.5 vs 3.7 ms).
+    pairs: None = FUSE_PAIRS for large-batch programs (not splitk): layer1's conv3 / next conv1 pairs as one launch.
     splitk: small-batch program (Engine.load_state_dict: max_batch < 16) - the low-resolution 3x3 layers are lowered
     with their input channels in slices that run as separate work items (ACRMI_CONV_SPLITK, splitk_slices()).
     keep_all: no buffer is reused, so every intermediate map can be read after a run (per-op parity tests; ~2x the
@@ -590,7 +657,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     c0 = backbone_channels(width)
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
-    P = Program(sd, dt, keep_weights, keep_all, wino24, splitk)
+    P = Program(sd, dt, keep_weights, keep_all, wino24, splitk, FUSE_PAIRS and not splitk if pairs is None else pairs)
     b = 'backbone.'
     taps = {}
     x34 = None
@@ -655,14 +722,13 @@ def _lower_hrnet(P, sd, b, STAGE_CFG, c0, keep_taps, keep_weights, taps):
         P.release(x0)
     # the stem's second conv writes channels 0..63 of a 128-channel map: layer1.0 puts its 3x3 output next to them and
     # takes conv3 and the projection shortcut as one 128 -> 256 convolution (Program.bottleneck)
-    cat = P.buf(128, 128, 128) if FUSE_PROJECTION else None
+    cat = P.buf(128, 128, 128) if (FUSE_PROJECTION and not P.pairs) else None
     x1 = P.conv_bn(x, b + 'conv2', b + 'bn2', 3, 2, True, out=cat)
     P.release(x)
     x = x1
     if keep_taps:
         taps['stem'] = P.pin(x)
-    for i in range(4):
-        x = P.bottleneck(x, b + 'layer1.%d' % i, cat=cat if i == 0 else None)
+    x = P.bottleneck_chain(x, b + 'layer1', 4, cat=cat)
     if keep_taps:
         taps['layer1'] = P.pin(x)
     # ---- stages ---------------------------------------------------------------------------------

@@ -67,6 +67,10 @@ enum {
                              map, aux = per-frame bias; w_off = 3 packed towers, w_off2 = mix weights);
                              acr/model.py:71-99,160-164 restricted to the pixels acr/result_parser.py:49-57,
                              141-145 samples */
+  ACRMI_OP_PAIR1X1 = 12,  /* two chained 1x1 convolutions of layer1 (acr/model.py:519-539) in one kernel: out = relu(W3 in +
+                             b3 + res) (64 -> 256 channels; in_buf, res_buf, out_buf) and aux = relu(W1 out + b1) (256 -> 64;
+                             aux_buf = the next block's conv1 output); w_off = packer.pack_pair1x1 (both matrices + biases in
+                             the kernel's LDS order, 33088 floats); fp32 programs */
   ACRMI_OP_MAXPOOL = 11,  /* max pooling 3x3 stride 2 pad 1 of cin channels (ResNet stem; in -> out [B,(H-1)/2+1,(W-1)/2+1]) */
   ACRMI_OP_STEM = 10      /* uint8 image -> relu(conv3x3 stride 2 (x/255*2-1) + b), 3 -> 64 channels: U8NORM + the
                              first CONV in one kernel (acr/model.py:832,589-603; in = the image, out = [B,H/2,W/2,>=64]);

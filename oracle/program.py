@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 OP_U8NORM, OP_CONV, OP_FUSESUM, OP_BILINEAR2X, OP_POW11, OP_ATTPOOL, OP_PAREBIAS, OP_COORDFILL, OP_POINTHEADS, OP_STEM = range(1, 11)
-OP_MAXPOOL = 11
+OP_MAXPOOL, OP_PAIR1X1 = 11, 12
 MODE_POINT = 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV (include/acrmi.h)
 CONV_SPLITK = 16
@@ -125,6 +125,17 @@ class Interp(object):
         r = hy_ * (hx_ * v00 + lx_ * v01) + ly_ * (hx_ * v10 + lx_ * v11)
         self.bufs[op.out_buf][..., op.out_coff:op.out_coff + op.cin] = rnd(r, self.dts[op.out_buf])
 
+    def pair1x1(self, op, info):
+        """out = relu(W3 in + b3 + res), aux = relu(W1 out + b1) (csrc/pair1x1.hip; fp32 programs)"""
+        (w3, b3), (w1, b1) = [(torch.from_numpy(np.asarray(w, np.float64)), torch.from_numpy(np.asarray(b, np.float64)))
+                              for (w, b) in info['wb']]
+        t2 = self.bufs[op.in_buf][..., op.in_coff:op.in_coff + 64].to(torch.float64)
+        y = torch.einsum('bhwc,oc->bhwo', t2, w3.reshape(256, 64)) + b3
+        y = torch.relu(y.to(torch.float32) + self.bufs[op.res_buf][..., op.res_coff:op.res_coff + 256])
+        self.bufs[op.out_buf][..., op.out_coff:op.out_coff + 256] = y
+        t = torch.einsum('bhwc,oc->bhwo', y.to(torch.float64), w1.reshape(64, 256)) + b1
+        self.bufs[op.aux_buf][..., :64] = torch.relu(t.to(torch.float32))
+
     def maxpool(self, op):
         x = self.bufs[op.in_buf][..., op.in_coff:op.in_coff + op.cin]
         y = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)      # exact in every storage type
@@ -185,6 +196,8 @@ class Interp(object):
                 self.bilinear2x(op)
             elif k == OP_MAXPOOL:
                 self.maxpool(op)
+            elif k == OP_PAIR1X1:
+                self.pair1x1(op, info)
             elif k == OP_POW11:
                 self.pow11(op)
             elif k == OP_COORDFILL:

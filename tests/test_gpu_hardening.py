@@ -163,6 +163,40 @@ def test_hostile_checkpoint_on_the_small_batch_lowering(mano_tables, frames2):
     eng.close()
 
 
+@pytest.mark.parametrize('law', ['benign', 'hostile'])
+def test_layer1_pair_kernel_matches_its_two_convolutions(law, frames2):
+    """OP_PAIR1X1 (csrc/pair1x1.hip; large-batch fp32 programs): block i's conv3 + residual + ReLU chained with block
+    i + 1's conv1 + ReLU, the second GEMM reading the first one's epilogue registers as its B operand.  The three pair ops
+    of layer1 are re-evaluated by the interpreter (exact fp64 products on the GPU's own input buffers): both outputs - the
+    256-channel map and the next block's 64-channel map - within fp32 accumulation-order tolerance, also on the hostile
+    checkpoint (stream activations of O(100))."""
+    synth = pkg('synth')
+    L = pkg('_lib')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth.make_state_dict(seed=0, law=law), max_batch=3, keep_weights=True, keep_all=True, wino24=True,
+                        splitk=False)
+    prog = eng.program
+    pairs = [(i, o) for i, o in enumerate(prog['ops']) if o.kind == L.OP_PAIR1X1]
+    assert len(pairs) == 3
+    x = torch.from_numpy(np.concatenate([frames2, frames2[:1]]))
+    B = eng.backbone_heads(x.cuda())
+    torch.cuda.synchronize()
+    hip = [eng.buffer(i, B).float().cpu() for i in range(len(prog['bufs']))]
+    it = oprog.Interp(prog, B)
+    it.bufs = [b.clone() for b in hip]
+    rep = {}
+    for i, op in pairs:
+        it.pair1x1(op, prog['op_info'][i])
+        for name, buf, n in (('out', op.out_buf, 256), ('aux', op.aux_buf, 64)):
+            want, got = it.bufs[buf][..., :n], hip[buf][..., :n]
+            err, scale = float((want - got).abs().max()), float(want.abs().max())
+            rep['%s.%s' % (prog['op_info'][i]['name'], name)] = [err, scale]
+            assert err <= 2e-6 * max(1.0, scale), (prog['op_info'][i]['name'], name, err, scale)
+        it.bufs[op.out_buf], it.bufs[op.aux_buf] = hip[op.out_buf].clone(), hip[op.aux_buf].clone()
+    _report('pair1x1_' + law, rep)
+    eng.close()
+
+
 def test_the_bench_batch_against_the_oracle(synth_sd, mano_tables):
     """the 64 i.i.d.-noise frames bench.py times (synth.make_frames(64, seed=0, structured=False))
     through the HIP path and through the oracle: decisions identical on every frame, vertices / joints within 1e-4 m on
