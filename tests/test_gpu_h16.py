@@ -66,6 +66,8 @@ H16_CASES = [
     (1, 32, 32, 19, 23, 3, 1, 1, True, False, False),       # ragged spatial size (tile bounds)
     (1, 40, 72, 21, 17, 3, 2, 1, False, False, False),      # ragged + stride 2
     (1, 24, 48, 9, 31, 1, 1, 1, True, False, False),
+    (2, 256, 512, 32, 32, 1, 2, 1, False, False, False),    # ResNet-50 projection shortcut: 1x1 stride 2
+    (1, 40, 72, 21, 17, 1, 2, 1, True, True, False),        # ... ragged, with a residual
 ]
 
 

@@ -42,6 +42,9 @@ CONV_CASES = [
     (1, 32, 32, 19, 23, 3, 1, 1, True, False),       # ragged spatial size (tile bounds)
     (1, 40, 70, 21, 17, 3, 2, 1, False, False),      # ragged + stride 2
     (1, 24, 48, 9, 31, 1, 1, 1, True, False),
+    (2, 256, 512, 32, 32, 1, 2, 1, False, False),    # ResNet-50 projection shortcut: 1x1 stride 2
+    (2, 64, 32, 16, 32, 1, 2, 1, True, False),       # ... one 32-cout tile
+    (1, 40, 70, 21, 17, 1, 2, 1, False, True),       # ... ragged, with a residual
 ]
 
 
@@ -455,7 +458,7 @@ def test_conv2d_rejects_unsupported(ops):
     with pytest.raises(ValueError):
         ops.conv2d(x, torch.zeros(8, 8, 5, 5))
     with pytest.raises(ValueError):
-        ops.conv2d(x, torch.zeros(8, 8, 1, 1), stride=2)
+        ops.conv2d(x, torch.zeros(8, 8, 1, 1), stride=3)
     with pytest.raises(ValueError):
         ops.conv2d(x, torch.zeros(8, 8, 3, 3), stride=2, algo='winograd2d')
 
