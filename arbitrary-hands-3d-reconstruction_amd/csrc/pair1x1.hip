@@ -37,7 +37,6 @@ __global__ __launch_bounds__(PR_WAVES * 64, 1) void pair1x1_kernel(const float* 
                                                          float* __restrict__ t, int t_cs, int t_coff,
                                                          const float* __restrict__ wpk, long npix) {
   extern __shared__ f32x4 smem4[];
-  float* lds = reinterpret_cast<float*>(smem4);
   // LDS: A1 [c 8][s4 8][lane 64][4] | A2 [c 8][nt 2][j4 4][lane 64][4] | b3 [c 8][g 4][h 2][4] | b1 [nt 2][g 4][h 2][4]
   const f32x4* a1 = smem4;
   const f32x4* a2 = smem4 + PR_C2 * PR_C1 / 4;

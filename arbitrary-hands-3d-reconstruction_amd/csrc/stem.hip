@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ST_TH = 8, ST_TW = 16, ST_STRIP = 4;
-constexpr int ST_PR = 2 * ST_TH + 1, ST_PC = 2 * ST_TW + 1;       // 17 x 33 input pixels per tile
+constexpr int ST_PR = 2 * ST_TH + 1;                             // 17 rows x 33 columns of input pixels per tile
 constexpr int ST_ROW = 100;                                       // floats per patch row: 33 * 3 + 1 zero slot
 constexpr int ST_PSTR = 36;
 
