@@ -162,7 +162,8 @@ __device__ __forceinline__ void ws_loader(const ConvArgs& a, const ConvWork& wk,
       for (int i = 0; i < NLD; ++i) {
         const int idx = ltid + i * NLT;
         const int pix = idx / (CK / 4);
-        const int iy = ty0 * S - PAD + pix / PW, ix = tx0 * S - PAD + pix % PW;
+        const int sub = a.in_sub > 1 ? a.in_sub : 1;      // (1x1 stride 2 as 1x1 stride 1 on every other row / column)
+        const int iy = (ty0 * S - PAD + pix / PW) * sub, ix = (tx0 * S - PAD + pix % PW) * sub;
         const bool ok = (idx < NLOAD) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
         off[i] = (iyc * a.W + ixc) * a.in_cs;   // per-frame offset < 2^31 floats

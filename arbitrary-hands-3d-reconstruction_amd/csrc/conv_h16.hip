@@ -517,9 +517,9 @@ hipError_t launch_conv_h16(ConvArgs a, hipStream_t s) {
     if (n32 || tiles8 * nb2 < cus) return launch_h16<3, 2, 8, 16, 4, 1, 1, 1, 16, 4>(a, s);
     return launch_h16<3, 2, 8, 16, 2, 2, 2, 1, 16, 4>(a, s);
   }
-  if (a.ks == 1 && a.stride == 2) {      // projection shortcut of a strided ResNet block
-    if (n32 || tiles8 * nb2 < cus) return launch_h16<1, 2, 8, 16, 4, 1, 1, 1, 32, 4>(a, s);
-    return launch_h16<1, 2, 8, 16, 2, 2, 2, 1, 32, 4>(a, s);
+  if (a.ks == 1 && a.stride == 2) {      // projection shortcut of a strided ResNet block: see launch_conv (in_sub)
+    a.stride = 1;                          // (a is already the float view: no second pass through this function)
+    a.in_sub = 2;
   }
   if (a.ks == 1 && a.stride == 1) {
     if (n32) return (small || tiles16 < cus) ? launch_h16<1, 1, 8, 16, 4, 1, 1, 1, 32, 2, true>(a, s)

@@ -607,10 +607,13 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     return launch_ws2<3, 2, 8, 16, 2, 2, 2, 1, 16, 2>(a, s);
   }
   if (a.ks == 1 && a.stride == 2) {
-    // the projection shortcut of a strided ResNet block (torchvision resnet.py downsample: 1x1 stride 2): the loader stages
-    // the whole 15x31-pixel patch, the tap reads every other pixel of it
-    if (n32) return launch_ws2<1, 2, 8, 16, 4, 1, 1, 1, 32, 2>(a, s);
-    return launch_ws2<1, 2, 8, 16, 2, 2, 2, 1, 32, 2>(a, s);
+    // the projection shortcut of a strided ResNet block (torchvision resnet.py downsample: 1x1 stride 2) = the 1x1
+    // stride-1 kernels on every other row and column of the input: only the loader's pixel coordinates change
+    // (ConvArgs.in_sub).  (First form: the <1, 2, ...> instantiation, which stages the whole 15x31-pixel patch - 47 TF.)
+    ConvArgs b = a;
+    b.stride = 1;
+    b.in_sub = 2;
+    return launch_conv(b, s);
   }
   if (a.ks == 1 && a.stride == 1) {
     if (n32) return (small || (fine && tiles16 < cus)) ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s)

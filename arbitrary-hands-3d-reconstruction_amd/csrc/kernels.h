@@ -36,6 +36,8 @@ struct ConvArgs {
   // Split-K (algo 2, small batches; conv_wino2.inc SPLIT): groups = K-slices of one convolution (slice s reads input
   // channels [s*Cin, (s+1)*Cin), all slices produce the same Cout channels).  split_ws: conv_splitk_ws_floats() floats,
   // split_cnt: conv_splitk_counters() zeroed unsigned, both private to the launches of one stream.
+  int in_sub;           // 2: the loader reads every other input row / column (a 1x1 stride-2 convolution runs as the 1x1
+                        // stride-1 kernel on the subsampled map; H, W stay the input's, Ho, Wo the output's); 0 / 1: dense
   int splitk;
   float* split_ws;
   unsigned* split_cnt;
