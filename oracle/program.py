@@ -11,7 +11,11 @@ op by op, in torch-CPU arithmetic on the un-packed folded filters the packer kee
     (the kernels accumulate in fp32: the difference is ~1e-7 relative, far below one 16-bit ulp, but it can move a
     value across a rounding boundary - comparisons allow a few ulps of the storage type), + bias (fp32, shared or per
     frame) + residual, ReLU;
-  * the element-wise ops follow the kernels' fp32 expressions term by term.
+  * the element-wise ops follow the kernels' fp32 expressions term by term;
+  * the lowering's own constructions are read back into the convolutions they stand for: a CONV with ACRMI_CONV_SPLITK is
+    ONE convolution over its concatenated K-slices, ACRMI_CONV_BIAS_MAP adds the position-bias map of the blob to every
+    frame, PAIR1X1 is two 1x1 convolutions (64 -> 256 + residual + ReLU, then 256 -> 64 + ReLU), MAXPOOL and the 7x7 stem
+    belong to the build-defined ResNet-50 (oracle/acr_net.resnet50_backbone).
 
 For fp32 W32 programs the same interpreter is cross-checked against oracle/acr_net.py (pinned to the reference), which
 pins the interpreter's reading of the op list; tests/test_program_oracle.py.
