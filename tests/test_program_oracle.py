@@ -197,3 +197,34 @@ def test_pack_stem7_layout():
         ky, kx, c = k // 21, (k % 21) // 3, k % 3
         assert frag[s, n, lh, li] == np.float32(w[32 * n + li, c, ky, kx])
     assert (frag[73, :, 1, :] == 0).all() and np.array_equal(bias, b.astype(np.float32))
+
+
+def test_layer1_pairs_are_lowered_only_where_they_pay(synth_sd):
+    """OP_PAIR1X1 (block i's conv3 + residual + ReLU chained with block i + 1's conv1): three pair ops in the large-batch fp32
+    program - whose interpreter reading is pinned to the oracle by the first test of this file - none in small-batch
+    (split-K) or 16-bit programs; with pairs, layer1.0 keeps its projection shortcut as a separate 1x1 conv, without them it
+    is folded into the block's last conv (128 -> 256)."""
+    packer, L = pkg('packer'), pkg('_lib')
+    big = packer.lower(synth_sd, point_heads=False)
+    names = [i['name'] for i in big['op_info']]
+    pairs = [o for o in big['ops'] if o.kind == L.OP_PAIR1X1]
+    assert len(pairs) == 3 and all(o.cin == 64 and o.cout == 256 and o.res_buf >= 0 and o.aux_buf >= 0 for o in pairs)
+    assert 'backbone.layer1.0.downsample.0' in names and 'backbone.layer1.1.conv1' not in names
+    assert 'backbone.layer1.3.conv3' in names                     # the last block ends in a plain conv
+    for kw in (dict(splitk=True, wino24=False), dict(precision='fp16'), dict(pairs=False)):
+        prog = packer.lower(synth_sd, point_heads=False, **kw)
+        assert not any(o.kind == L.OP_PAIR1X1 for o in prog['ops']), kw
+        assert 'backbone.layer1.0.conv3+downsample' in [i['name'] for i in prog['op_info']], kw
+    # the packed LDS image: both matrices in the kernel's k orders
+    rs = np.random.RandomState(2)
+    w3, b3, w1, b1 = rs.randn(256, 64), rs.randn(256), rs.randn(64, 256), rs.randn(64)
+    img = packer.pack_pair1x1(w3, b3, w1, b1)
+    a1 = img[:16384].reshape(8, 8, 64, 4)
+    a2 = img[16384:32768].reshape(8, 2, 4, 64, 4)
+    for c, s4, lane, e in ((0, 0, 0, 0), (3, 5, 40, 2), (7, 7, 63, 3)):
+        m, h = lane % 32, lane // 32
+        assert a1[c, s4, lane, e] == np.float32(w3[32 * c + m, 32 * h + 4 * s4 + e])
+    for c, nt, g, lane, e in ((0, 0, 0, 0, 0), (5, 1, 2, 37, 1), (7, 1, 3, 63, 3)):
+        m, h = lane % 32, lane // 32
+        assert a2[c, nt, g, lane, e] == np.float32(w1[32 * nt + m, 32 * c + 8 * g + 4 * h + e])
+    assert np.array_equal(img[32768:32768 + 256], b3.astype(np.float32)) and np.array_equal(img[-64:], b1.astype(np.float32))
