@@ -175,6 +175,61 @@ def test_conv2d_winograd24_matches_torch(ops, case):
         assert out[..., cout:].abs().max().item() == 0.0
 
 
+WINO24B_CASES = [
+    # (B, Cin, Cout, H, W, groups, relu, residual kind: 0 none / 1 per frame / 2 one map for every frame, frame_bias)
+    (2, 64, 64, 64, 64, 1, True, 1, False),        # HRNet branch 1: two chunks, all four border kinds
+    (20, 64, 64, 64, 64, 1, True, 1, False),       # 320 items: more than one item per workgroup
+    (3, 128, 128, 32, 32, 1, True, 0, False),      # branch 2: four chunks, two n-blocks, every tile touches left AND right
+    (1, 512, 512, 64, 64, 8, True, 1, False),      # the eight head towers as groups
+    (2, 96, 128, 8, 32, 1, False, 2, False),       # three chunks, one tile per frame (all four borders), no ReLU, map residual
+    (2, 64, 64, 16, 96, 1, False, 0, True),        # interior tile columns, per-frame bias rows
+    (1, 64, 192, 24, 64, 1, True, 1, True),        # three n-blocks
+]
+
+
+@pytest.mark.parametrize('case', WINO24B_CASES, ids=lambda c: 'wino24b_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv2d_winograd24_four_wave_frame(ops, case):
+    """conv_wino24b_kernel (F(2x4,3x3) on the four-wave / 512-register frame: two n-tiles per wave, LDS-DMA patches
+    issued by the compute waves, early chunk barrier) vs an fp64 direct convolution AND bit for bit vs conv_wino24_kernel
+    (acrmi_tune cfg 840 keeps the old frame: same products in the same order).  Input, residual and output live in
+    channel slices of wider buffers; the neighbour channels must stay untouched."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    L = pkg('_lib').lib()
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 240)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 3, 3, generator=g) / np.sqrt(cin // groups * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 1, 1, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B if res_kind == 1 else 1, cout, H, W), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    outs = []
+    for cfg in (-1, 840):
+        dst = torch.full((B, H, W, cout + 16), 7.0, device='cuda')     # output into channels 8..
+        L.acrmi_tune(0, cfg)
+        try:
+            ops.conv2d(xin, w, None if use_fb else b, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo='winograd24',
+                       out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                       frame_bias=None if fb is None else fb.cuda())
+            torch.cuda.synchronize()
+        finally:
+            L.acrmi_tune(0, -1)
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        err = (got.double() - ref).abs().max().item()
+        assert err < 2e-4, (cfg, err)
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), cfg
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
 WINO3_CASES = [
     # B, Cin, H, W, relu, residual
     (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)

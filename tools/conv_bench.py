@@ -62,7 +62,7 @@ def main():
     B = args.batch
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     for name, cin, cout, H, W, k, stride, groups, use_res in SHAPES:
-        if args.filter not in name:
+        if not any(f in name for f in args.filter.split(',')):
             continue
         cing, coutg = cin // groups, cout // groups
         if args.h16:
