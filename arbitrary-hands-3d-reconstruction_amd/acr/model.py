@@ -10,14 +10,14 @@ import torch
 from ..config import args, validate
 from ..engine import Engine
 from ..schema import RESNET50, backbone_channels, state_dict_schema, width_of
-from .result_parser import ResultParser, rows_from_slots
+from .result_parser import ResultParser, reference_prior_gate, rows_from_slots
 
 
 class ACR(object):
     def __init__(self, device=0, max_batch=1, **kwargs):
         self._args = validate(args())
         self._retired = None
-        self._result_parser = ResultParser()
+        self._result_parser = ResultParser(batch_semantics=kwargs.get('batch_semantics'))
         self.params_num = self._result_parser.params_num
         self._init_sd(kwargs.get('width', RESNET50 if getattr(self._args, 'backbone', 'hrnet') == RESNET50 else 32))
         self._device = device
@@ -130,6 +130,10 @@ class ACR(object):
         B = eng.backbone_heads(img.contiguous())
         outputs = eng.head_maps(B) if cfg.get('return_maps', True) else {}
         outputs['slots'] = eng.decode(B)
+        if self._result_parser.batch_semantics == 'reference' and B > 1:
+            # the reference's batch-wide prior rules (acr/result_parser.py:42-47,131): decided on the host from the first
+            # decode's flags / centers, applied by a second decode (result_parser.reference_prior_gate)
+            outputs['slots'] = eng.decode(B, prior_gate=reference_prior_gate(outputs['slots'], self._result_parser.map_size))
         if 'batch_ids' not in meta_data:
             meta_data['batch_ids'] = torch.arange(B)
         outputs.update(rows_from_slots(outputs['slots'], meta_data, self._result_parser.map_size))

@@ -2,9 +2,12 @@
 decode kernel.  The kernel writes fixed per-(frame,hand) slots; this module re-packs them into the
 reference's variable-length rows: all left rows (ascending frame), then all right rows.
 
-Semantics are per frame (= the reference run at batch 1 for every frame, the only way
-acr/main.py:126-141 calls it).  The reference's batch>1 quirks - prior gated on *every* flag of the
-batch (:131), determine_coeff reading row 0 only (:42-47) - are not reproduced.
+Default semantics are per frame (= the reference run at batch 1 for every frame, the only way
+acr/main.py:126-141 calls it).  ResultParser(batch_semantics='reference') / args().batch_semantics
+= 'reference' reproduces what the reference's parse_maps does when it is handed a batch > 1: the
+cross-hand prior only when EVERY flag of the batch is set (:131) and determine_coeff deciding for
+the whole batch from row 0 of each side's list (:42-47) - see reference_prior_gate below.  (The
+whole-batch placeholder rows, :102-120, are reproduced in both modes.)
 """
 import numpy as np
 import torch
@@ -67,9 +70,37 @@ def rows_from_slots(slots, meta_data=None, map_size=64):
     return out
 
 
+def reference_prior_gate(slots, map_size=64):
+    """The reference's batch-wide prior decision (acr/result_parser.py:85-145) from a first decode's flags / centers.
+    slots [B,2,176] -> int32 [B] on slots' device: 1 = this frame's two rows take their cross-hand prior, 0 = not.
+      * l_ids / r_ids = frames whose left / right center passed the threshold (ascending);
+      * no prior at all unless both lists are non-empty - a side with no hit in the WHOLE batch carries a placeholder
+        row whose flag is False, and :131 wants sum(detection_flag) == len(detection_flag);
+      * determine_coeff (:42-47) compares l_cyxs[0] with r_cyxs[0]: the left center of the FIRST left-detected frame
+        and the right center of the FIRST right-detected frame (not necessarily the same frame); more than 32 map
+        pixels apart -> both priors become 0 for every frame of the batch;
+      * otherwise the prior is added exactly in the frames that have both hands (all_hand_valid_batch_ids, :128)."""
+    flag = (slots[:, :, _lib.SLOT_FLAG] > 0.5).cpu()
+    flat = slots[:, :, _lib.SLOT_FLATIND].long().cpu()
+    B = flag.shape[0]
+    gate = torch.zeros(B, dtype=torch.int32)
+    l_ids, r_ids = torch.nonzero(flag[:, 0]).flatten(), torch.nonzero(flag[:, 1]).flatten()
+    if l_ids.numel() and r_ids.numel():
+        fl, fr = int(flat[l_ids[0], 0]), int(flat[r_ids[0], 1])
+        dy, dx = float(fl // map_size - fr // map_size), float(fl % map_size - fr % map_size)
+        if not (dy * dy + dx * dx) ** 0.5 > 32:
+            gate[flag[:, 0] & flag[:, 1]] = 1
+    return gate.to(slots.device)
+
+
 class ResultParser(object):
-    def __init__(self):
+    def __init__(self, batch_semantics=None):
+        """batch_semantics: 'frame' (default; every frame as the reference treats a batch of one) or 'reference' (the
+        reference's batch-wide prior rules at batch > 1); None = args().batch_semantics."""
         a = args()
+        self.batch_semantics = batch_semantics or getattr(a, 'batch_semantics', 'frame')
+        if self.batch_semantics not in ('frame', 'reference'):
+            raise ValueError("batch_semantics %r: 'frame' or 'reference'" % (self.batch_semantics,))
         self.map_size = a.centermap_size
         self.conf_thresh = a.centermap_conf_thresh          # CenterMap.conf_thresh (acr/result_parser.py:198-205)
         self.part_name = ['cam', 'global_orient', 'hand_pose', 'betas']
@@ -90,8 +121,12 @@ class ResultParser(object):
             from .. import ops
             m = {k: ops.to_nhwc(outputs[k], device=outputs[k].device) for k in
                  ('l_center_map', 'r_center_map', 'l_params_maps', 'r_params_maps', 'l_prior_maps', 'r_prior_maps')}
-            slots = ops.decode_maps(m['l_center_map'], m['r_center_map'], m['l_params_maps'], m['r_params_maps'],
-                                    m['l_prior_maps'], m['r_prior_maps'], conf_thresh=self.conf_thresh)
+            dec = lambda gate: ops.decode_maps(m['l_center_map'], m['r_center_map'], m['l_params_maps'], m['r_params_maps'],
+                                               m['l_prior_maps'], m['r_prior_maps'], conf_thresh=self.conf_thresh,
+                                               prior_gate=gate)
+            slots = dec(None)
+            if self.batch_semantics == 'reference' and slots.shape[0] > 1:
+                slots = dec(reference_prior_gate(slots, self.map_size))
             outputs['slots'] = slots
         outputs.update(rows_from_slots(slots, meta_data, self.map_size))
         return outputs, meta_data

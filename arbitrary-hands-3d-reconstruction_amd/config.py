@@ -18,6 +18,9 @@ DEFAULTS = dict(
     mano_mesh_root_align=True, perspective_proj=False, focal_length=1265, temporal_optimization=False,
     smooth_coeff=4.0, save_dict_results=False, save_visualization_on_img=False, val_batch_size=1, GPUS=0,
     renderer='none', render_size=512,
+    # not a reference flag: 'frame' = every frame as a batch of one (default); 'reference' = the reference's batch-wide
+    # prior rules when a batch > 1 is parsed (acr/result_parser.py:42-47,131; result_parser.reference_prior_gate)
+    batch_semantics='frame',
 )
 
 _ARGS = argparse.Namespace(**copy.deepcopy(DEFAULTS))
@@ -83,6 +86,8 @@ def validate(ns):
     # inference always takes the top-1 center per map, whatever the reference's default of 4 says)
     if not (isinstance(ns.align_idx, int) and 0 <= ns.align_idx <= 20):
         raise ValueError('align_idx must be a joint index 0..20')
+    if getattr(ns, 'batch_semantics', 'frame') not in ('frame', 'reference'):
+        raise ValueError("batch_semantics %r: 'frame' or 'reference'" % (ns.batch_semantics,))
     if ns.model_precision not in ('fp32', 'fp16', 'bf16'):
         # acr/config.py:96: fp32 (configs/demo.yml) | fp16 (the argparse default: autocast, acr/model.py:33-37);
         # bf16 = the same 16-bit program on the other gfx950 MFMA type (packer.lower)

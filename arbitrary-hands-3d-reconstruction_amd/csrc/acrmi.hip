@@ -51,7 +51,7 @@ struct acrmi_ctx {
   int want_lanes = 0;           // 0 = by batch size (AUTO_LANES_*)
   // ACRMI_OPT_LANE_PLAN: lane per op from MEASURED op times (acrmi_profile_ops at a small batch stores them here), small-
   // batch schedules only; empty = the structural heuristic
-  bool lane_plan = true;
+  bool lane_plan = false;       // (explicit: Engine.tune_lanes / the host switches it on after profiling)
   std::vector<float> op_ms[2];  // [point]: per-op milliseconds of the last small-batch profile
   hipStream_t lanes[MAX_LANES] = {};
   hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {};
@@ -554,7 +554,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         return fail(c, ACRMI_EINVAL, "op %d: algo 3 needs groups 1, Cin <= 32, Cout = 32, a map of 8x16-pixel tiles", i);
       const int ogroups = splitk ? 1 : op.groups;      // the slices of a split-K conv share the output channels
       if (op.in_coff + op.groups * op.cin > bufs[op.in_buf].cs || op.out_coff + ogroups * op.cout > bufs[op.out_buf].cs ||
-          (op.res_buf >= 0 && op.res_coff + ogroups * op.cout > bufs[op.res_buf].cs) || (op.groups > 1 && op.cin % 4))
+          (op.res_buf >= 0 && op.res_coff + ogroups * op.cout > bufs[op.res_buf].cs) ||
+          (op.groups > 1 && op.cin % (bufs[op.in_buf].dtype == ACRMI_DT_F32 ? 4 : 8)))      // a group starts on a 16-byte vector
         return fail(c, ACRMI_EINVAL, "op %d: channel slice outside its buffer's channel stride", i);
       const int pad = op.ksize / 2;
       const int ho = (bufs[op.in_buf].h + 2 * pad - op.ksize) / op.stride + 1, wo = (bufs[op.in_buf].w + 2 * pad - op.ksize) / op.stride + 1;
@@ -759,6 +760,7 @@ int acrmi_load_mano(acrmi_ctx* c, int side, const float* v_template, const float
 static unsigned lane_event_flags() {
   static const unsigned f = [] {
     const char* e = getenv("ACRMI_EVENT_FLAGS");      // experiment switch: extra hipEventCreateWithFlags bits (hex)
+    if (e) fprintf(stderr, "[acrmi] WARNING: ACRMI_EVENT_FLAGS=%s - lane events created with non-default flags (experiment)\n", e);
     return hipEventDisableTiming | (e ? (unsigned)strtoul(e, nullptr, 16) : 0u);
   }();
   return f;
@@ -777,7 +779,15 @@ static int run_program_lanes(acrmi_ctx* c, const uint8_t* img, int B, hipStream_
   int r = ACRMI_OK;
   for (int j : S.order) {
     hipStream_t s = st(S.lane[j]);
-    static const int ablate = getenv("ACRMI_ABLATE_LANE_SYNC") ? atoi(getenv("ACRMI_ABLATE_LANE_SYNC")) : 0;   // timing ablation (WRONG results): 1 = no waits, 2 = no waits and no records
+    // timing ablation (WRONG results: data races between lanes): 1 = no waits, 2 = no waits and no records.  Loud, so that a
+    // leaked environment variable cannot silently corrupt a real run.
+    static const int ablate = [] {
+      const char* e = getenv("ACRMI_ABLATE_LANE_SYNC");
+      const int v = e ? atoi(e) : 0;
+      if (v) fprintf(stderr, "[acrmi] WARNING: ACRMI_ABLATE_LANE_SYNC=%d - cross-lane synchronisation is DISABLED, results are WRONG "
+                             "(timing experiment only)\n", v);
+      return v;
+    }();
     if (!(ablate & 1)) for (int d : S.wait[j]) HIPCHK(c, hipStreamWaitEvent(s, c->op_ev[d], 0));
     r = run_op(c, c->ops[j], img, B, s, S.lane[j]);
     if (r) break;
@@ -968,9 +978,9 @@ int acrmi_buffer_dtype(acrmi_ctx* c, int buf) {
   return c->bufs[buf].dtype;
 }
 
-int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs, const float* l_params,
-                      const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
-                      int B, float conf_thresh, float* slots, void* stream) {
+int acrmi_decode_maps_gated(const float* l_center, const float* r_center, int center_cs, const float* l_params,
+                            const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
+                            int B, float conf_thresh, const int32_t* prior_gate, float* slots, void* stream) {
   if (!l_center || !r_center || !l_params || !r_params || !l_prior || !r_prior || !slots || B <= 0 || params_cs < 109 ||
       prior_cs < 106 || center_cs < 1 || !(conf_thresh == conf_thresh))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_decode_maps: bad arguments");
@@ -979,21 +989,31 @@ int acrmi_decode_maps(const float* l_center, const float* r_center, int center_c
   d.params[0] = l_params; d.params[1] = r_params; d.params_cs = params_cs;
   d.prior[0] = l_prior; d.prior[1] = r_prior; d.prior_cs = prior_cs;
   d.B = B; d.slots = slots; d.thresh = conf_thresh;
+  d.prior_gate = prior_gate;
   hipError_t e = launch_decode(d, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "decode launch: %s", hipGetErrorString(e));
   return ACRMI_OK;
 }
 
-int acrmi_decode(acrmi_ctx* c, int B, float* slots, void* stream) {
+int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs, const float* l_params,
+                      const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
+                      int B, float conf_thresh, float* slots, void* stream) {
+  return acrmi_decode_maps_gated(l_center, r_center, center_cs, l_params, r_params, params_cs, l_prior, r_prior, prior_cs, B,
+                                 conf_thresh, nullptr, slots, stream);
+}
+
+int acrmi_decode(acrmi_ctx* c, int B, float* slots, void* stream) { return acrmi_decode_gated(c, B, nullptr, slots, stream); }
+
+int acrmi_decode_gated(acrmi_ctx* c, int B, const int32_t* prior_gate, float* slots, void* stream) {
   if (!c || !slots) return fail(c, ACRMI_EINVAL, "acrmi_decode: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_decode: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
   ON_DEVICE(c);
   const acrmi_head_layout& h = c->heads;
-  int r = acrmi_decode_maps(c->buf_ptr[h.center_buf[0]], c->buf_ptr[h.center_buf[1]], c->bufs[h.center_buf[0]].cs,
-                            c->buf_ptr[h.params_buf[0]], c->buf_ptr[h.params_buf[1]], c->bufs[h.params_buf[0]].cs,
-                            c->buf_ptr[h.prior_buf[0]], c->buf_ptr[h.prior_buf[1]], c->bufs[h.prior_buf[0]].cs, B,
-                            c->conf_thresh, slots, stream);
+  int r = acrmi_decode_maps_gated(c->buf_ptr[h.center_buf[0]], c->buf_ptr[h.center_buf[1]], c->bufs[h.center_buf[0]].cs,
+                                  c->buf_ptr[h.params_buf[0]], c->buf_ptr[h.params_buf[1]], c->bufs[h.params_buf[0]].cs,
+                                  c->buf_ptr[h.prior_buf[0]], c->buf_ptr[h.prior_buf[1]], c->bufs[h.prior_buf[0]].cs, B,
+                                  c->conf_thresh, prior_gate, slots, stream);
   if (r) c->err = g_err;
   return r;
 }
@@ -1144,7 +1164,7 @@ int acrmi_conv2d_h16(const void* in, int B, int H, int W, int in_cs, int in_coff
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (out_f32 && stride != 1))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: 3x3 and 1x1 at stride 1 / 2 (fp32 output: stride 1 only); got k%d s%d", ksize, stride);
   const int oq = out_f32 ? 4 : 8;      // elements per 16-byte vector of the output / residual
-  if (in_cs % 8 || in_coff % 8 || (groups > 1 && cin % 2) || out_cs % oq || (res && res_cs % oq))
+  if (in_cs % 8 || in_coff % 8 || (groups > 1 && cin % 8) || out_cs % oq || (res && res_cs % oq))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d_h16: channel strides must be multiples of 16 bytes");
   if (in_coff < 0 || out_coff < 0 || res_coff < 0 || in_coff + groups * cin > in_cs || out_coff + groups * cout > out_cs ||
       (res && res_coff + groups * cout > res_cs) || bias_frame_stride < 0 ||

@@ -328,7 +328,7 @@ struct PickScratch {
   int besti[2][4];
 };
 __device__ inline void pick_centers(const float* const* center, int center_cs, int b, float thresh, PickScratch& sc,
-                                    CenterPick& pk) {
+                                    CenterPick& pk, const int* prior_gate = nullptr) {
   const int tid = threadIdx.x;
   for (int h = 0; h < 2; ++h)
     for (int i = tid; i < 4096; i += 256) sc.cmap[h][i] = center[h][((size_t)b * 4096 + i) * center_cs];
@@ -372,6 +372,7 @@ __device__ inline void pick_centers(const float* const* center, int center_cs, i
       const float dx = (float)(pk.flat[0] & 63) - (float)(pk.flat[1] & 63);
       if (sqrtf(dy * dy + dx * dx) > 32.f) use = 0;
     }
+    if (prior_gate && prior_gate[b] >= 0) use = (pk.flag[0] && pk.flag[1]) ? (prior_gate[b] != 0) : 0;   // caller's batch-wide decision
     pk.prior = use;
   }
   __syncthreads();
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
   __shared__ PickScratch sc;
   __shared__ CenterPick pk;
   __shared__ float pred[2][112];
-  pick_centers(a.center, a.center_cs, b, a.thresh, sc, pk);
+  pick_centers(a.center, a.center_cs, b, a.thresh, sc, pk, a.prior_gate);
   const int* s_flat = pk.flat;
   const int* s_flag = pk.flag;
   const float* s_score = pk.score;

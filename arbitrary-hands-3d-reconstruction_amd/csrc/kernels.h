@@ -135,6 +135,9 @@ struct DecodeArgs {
   int B;
   float* slots;
   float thresh;          // centermap_conf_thresh (acr/result_parser.py:241), strict >
+  const int* prior_gate; // null: the cross-hand prior is decided per frame (both hands found, centers <= 32 px apart);
+                         // else [B]: < 0 = per frame, 0 = no prior, 1 = prior whenever the frame has both hands (the caller
+                         // has applied the reference's batch-wide rules, acr/result_parser.py:42-47,131)
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
 

@@ -29,7 +29,7 @@ class Engine(object):
         self.have_mano = False
         self.point_heads = False
         self.lanes = 0
-        self.lane_plan = True
+        self.lane_plan = False
         self.conf_thresh = 0.35
         self.center_idx = 9
         self.temporal = False
@@ -86,12 +86,22 @@ class Engine(object):
                                                 max_batch), self.ctx)
         self.max_batch = max_batch
 
+    @property
+    def has_point_heads(self):
+        """True when the loaded program carries the point-heads variant (packer.lower emits it for fp32 HRNet-W32
+        programs only: 16-bit programs, HRNet-W48 and the ResNet-50 backbone run the dense heads)."""
+        prog = getattr(self, 'program', None)
+        return bool(prog) and any(o.kind == _lib.OP_POINTHEADS for o in prog['ops'])
+
     def set_point_heads(self, on):
         """ACRMI_OPT_POINT_HEADS: `forward` evaluates the params/cam/prior head towers and the mix conv only at the
         pixels ResultParser samples (acr/result_parser.py:49-57,141-145).  Same slots / vertices up to fp32
-        round-off; `head_maps` params/prior maps are then only valid after `backbone_heads` (always dense)."""
-        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_POINT_HEADS, int(bool(on))), self.ctx)
-        self.point_heads = bool(on)
+        round-off; `head_maps` params/prior maps are then only valid after `backbone_heads` (always dense).
+        Returns what is in effect: a program without the point-heads ops stays on its dense heads (same results)."""
+        on = bool(on) and self.has_point_heads
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_POINT_HEADS, int(on)), self.ctx)
+        self.point_heads = on
+        return on
 
     def set_lanes(self, n):
         """ACRMI_OPT_LANES: independent chains of the program on n parallel HIP streams (1 = single stream,
@@ -139,7 +149,12 @@ class Engine(object):
                 ms[(int(n), planned)] = (time.perf_counter() - t0) / calls * 1e3
         best = min(ms, key=ms.get)
         self.set_lane_plan(best[1])
-        self.set_lanes(0 if best[0] == (4 if batch < 32 else 2) else best[0])
+        # The measurement was taken at `batch`; it only overrides the library's choice for contexts that serve such batches
+        # (max_batch <= 32 = the library's small-batch schedule: 4 lanes up to 32 frames, 2 above).  A context built for
+        # large batches keeps "by batch size": a batch-1 winner of 1 or 6 lanes must not replace the 2 lanes of its
+        # 64-frame calls.
+        small_ctx = self.max_batch <= 32
+        self.set_lanes(best[0] if small_ctx and best[0] != (4 if batch <= 32 else 2) else 0)
         return best, ms
 
     def set_conf_thresh(self, thresh):
@@ -281,9 +296,17 @@ class Engine(object):
             out = {k: v.permute(0, 3, 1, 2).contiguous() for k, v in out.items()}
         return out
 
-    def decode(self, B):
+    def decode(self, B, prior_gate=None):
+        """prior_gate: int32 device tensor [B] (acrmi_decode_gated: < 0 per-frame rule, 0 no prior, 1 prior when the frame
+        has both hands) - how acr.result_parser applies the reference's batch-wide prior rules; None = per frame."""
         slots = torch.empty(B, 2, _lib.SLOT, dtype=torch.float32, device=self.device)
-        _lib.check(self.L.acrmi_decode(self.ctx, B, _ptr(slots), _stream(self.device)), self.ctx)
+        if prior_gate is None:
+            _lib.check(self.L.acrmi_decode(self.ctx, B, _ptr(slots), _stream(self.device)), self.ctx)
+        else:
+            g = prior_gate.to(device=self.device, dtype=torch.int32).contiguous()
+            if g.numel() != B:
+                raise ValueError('prior_gate must hold one int per frame')
+            _lib.check(self.L.acrmi_decode_gated(self.ctx, B, _ptr(g), _ptr(slots), _stream(self.device)), self.ctx)
         return slots
 
     def mano(self, poses, betas, side, center_idx=9, cam=None, offsets=None):

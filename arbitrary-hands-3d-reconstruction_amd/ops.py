@@ -256,12 +256,16 @@ def parebias(pooled, lc_w, lin_w, lin_b, mix_wp, mix_b, part0):
     return out
 
 
-def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior, conf_thresh=0.35):
-    """NHWC device maps -> slots [B,2,176].  conf_thresh = args().centermap_conf_thresh (strict >)."""
-    _need_cuda(l_center, r_center, l_params, r_params, l_prior, r_prior)
+def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior, conf_thresh=0.35, prior_gate=None):
+    """NHWC device maps -> slots [B,2,176].  conf_thresh = args().centermap_conf_thresh (strict >).
+    prior_gate: int32 device tensor [B] (acrmi_decode_maps_gated) or None = the per-frame prior rule."""
+    _need_cuda(l_center, r_center, l_params, r_params, l_prior, r_prior, prior_gate)
     B = l_center.shape[0]
     slots = torch.empty(B, 2, _lib.SLOT, dtype=torch.float32, device=l_center.device)
-    _lib.check(_lib.lib().acrmi_decode_maps(_p(l_center), _p(r_center), l_center.shape[-1], _p(l_params), _p(r_params),
-                                            l_params.shape[-1], _p(l_prior), _p(r_prior), l_prior.shape[-1], B,
-                                            float(conf_thresh), _p(slots), _s(slots)))
+    gate = None if prior_gate is None else prior_gate.to(torch.int32).contiguous()
+    if gate is not None and gate.numel() != B:
+        raise ValueError('prior_gate must hold one int per frame')
+    _lib.check(_lib.lib().acrmi_decode_maps_gated(_p(l_center), _p(r_center), l_center.shape[-1], _p(l_params), _p(r_params),
+                                                  l_params.shape[-1], _p(l_prior), _p(r_prior), l_prior.shape[-1], B,
+                                                  float(conf_thresh), _p(gate), _p(slots), _s(slots)))
     return slots

@@ -280,7 +280,14 @@ def splitk_slices(k, stride, cin, cout, groups, ho, wo, per_frame_bias):
         return 1
     n_tiles = 1 if cout <= 32 else (cout + 63) // 64 * 2
     items = ((ho + 7) // 8) * ((wo + 15) // 16) * n_tiles
-    return min(cin // 64, 8) if items <= SPLITK_MAX_ITEMS else 1
+    if items > SPLITK_MAX_ITEMS:
+        return 1
+    # the largest slice count <= 8 whose slices are whole 32-channel chunks (the kernel needs Cin % 32 == 0 per slice:
+    # 576 or 640 input channels must not become 9 or 10 ragged slices cut down to 8)
+    for s in range(min(cin // 64, 8), 1, -1):
+        if cin % (32 * s) == 0:
+            return s
+    return 1
 
 
 # layer1.0's projection shortcut as extra input channels of its last 1x1 conv (Program.bottleneck): batch 64, fp32:

@@ -176,6 +176,12 @@ int acrmi_buffer_dtype(acrmi_ctx* ctx, int buf);
 /* acr/result_parser.py:21-40,85-190 (ResultParser.parse/parse_maps) + acr/utils.py:334-382
  * (6D -> axis-angle), per-frame semantics: slots_dev [B,2,ACRMI_SLOT]. */
 int acrmi_decode(acrmi_ctx* ctx, int B, float* slots_dev, void* stream);
+/* The same with the cross-hand prior decided by the CALLER per frame: prior_gate_dev [B] int32 on the device (NULL = as
+ * acrmi_decode): < 0 = this frame by the per-frame rule, 0 = no prior, 1 = prior when the frame has both hands.  This is how
+ * the host reproduces the reference's batch > 1 behaviour (acr/result_parser.py:131: the prior only when EVERY flag of the
+ * batch is set; :42-47: determine_coeff reads row 0 of each side's list) - acr/result_parser.py ResultParser(batch_semantics=
+ * 'reference') decodes once, applies those batch-wide rules to the flags / centers, and decodes again with the gate. */
+int acrmi_decode_gated(acrmi_ctx* ctx, int B, const int32_t* prior_gate_dev, float* slots_dev, void* stream);
 
 /* Same decode on caller-supplied NHWC maps (unit tests / callers with their own maps):
  * center [B,64,64,center_cs] (ch 0), params [B,64,64,params_cs] (109 ch), prior (106 ch). */
@@ -184,6 +190,10 @@ int acrmi_decode_maps(const float* l_center, const float* r_center, int center_c
                       const float* l_prior, const float* r_prior, int prior_cs, int B,
                       float conf_thresh /* CenterMap.conf_thresh = args().centermap_conf_thresh, 0.35 */,
                       float* slots_dev, void* stream);
+int acrmi_decode_maps_gated(const float* l_center, const float* r_center, int center_cs,
+                            const float* l_params, const float* r_params, int params_cs,
+                            const float* l_prior, const float* r_prior, int prior_cs, int B, float conf_thresh,
+                            const int32_t* prior_gate_dev /* see acrmi_decode_gated */, float* slots_dev, void* stream);
 
 /* mano/manolayer.py:104-276 (ManoLayer.forward, use_pca=False, flat_hand_mean=False,
  * center_idx as given; <0 = no root alignment) fused with acr/utils.py:384-412
@@ -293,7 +303,8 @@ int acrmi_parebias(const float* pooled_dev, int C, int part0, const float* lc_w_
  * acrmi_load_mano - half the table traffic per hand; all products and sums stay fp32, v_template / J_regressor / the
  * kinematic chain are untouched.  Measured deviation from the fp32 tables: see tests/test_gpu_h16.py. */
 #define ACRMI_OPT_MANO_FP16 7
-/* ACRMI_OPT_LANE_PLAN (0/1, default 1): once acrmi_profile_ops has run at a small batch (<= 32 frames), the lanes of the
+/* ACRMI_OPT_LANE_PLAN (0/1, default 0 - planning is explicit): once acrmi_profile_ops has run at a small batch (<= 32 frames;
+ * it stores the op times of the head mode that was active, dense or point, measured on one stream), the lanes of the
  * small-batch schedules are assigned by list scheduling over the MEASURED per-op times (every op goes to the lane where
  * it can start first; a cross-stream dependency is charged what it costs on MI355X, ~16 us over an in-stream one)
  * instead of by the structure of the graph alone.  Results do not depend on the assignment.  0 = structural only. */
@@ -332,7 +343,9 @@ int acrmi_allgather(acrmi_ctx* ctx, void* nccl_comm, const float* send_dev, floa
 int acrmi_point_heads(acrmi_ctx* ctx, int B, void* stream);
 
 /* Profiling aid for bench.py: time every op of the program with hipEvents on `stream`
- * (one untimed warm-up pass first; ops outside the active head mode report 0).  ms_out[n_ops]; returns n_ops or <0. */
+ * (one untimed warm-up pass first; ops outside the active head mode report 0).  ms_out[n_ops]; returns n_ops or <0.
+ * At a small batch (<= 32 frames) the times are also kept in the context (per head mode) as the input of
+ * ACRMI_OPT_LANE_PLAN; they change how later calls are scheduled only after that option has been switched on. */
 int acrmi_profile_ops(acrmi_ctx* ctx, const uint8_t* img_dev, int B, float* ms_out, int n_ms, void* stream);
 
 /* A non-blocking HIP stream on `device` / its release - for hosts without a stream API of their own (the Python

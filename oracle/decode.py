@@ -1,11 +1,11 @@
 """ORACLE (test infrastructure, not product): CPU restatement of the ACR decode step.
 
 center-map NMS / top-1 / threshold, parameter sampling, cross-hand prior, 109-split and
-6D -> axis-angle, with PER-FRAME semantics (= the reference run N times at batch 1,
-which is the only way acr/main.py:126-141 ever calls it).  The reference's batch>1
-quirks (placeholder only when a side has zero hits in the whole batch, prior gated on
-every flag in the batch, determine_coeff reading row 0 only;
-acr/result_parser.py:42-47,102-131) are deliberately not reproduced; DESIGN.md says so.
+6D -> axis-angle.  decode(maps) has PER-FRAME semantics (= the reference run N times at batch 1,
+which is the only way acr/main.py:126-141 ever calls it); decode(maps, batch_semantics='reference')
+restates what the reference's parse_maps does with a batch > 1 (prior gated on every flag of the
+batch, determine_coeff reading row 0 of each side's list; acr/result_parser.py:42-47,131) and
+slots_to_rows_batch the whole-batch placeholder rows (:102-120) - pinned by tests/golden/decode_batches.npz.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -83,9 +83,33 @@ def sample(maps, b, flat):
     return maps[b].reshape(maps.shape[1], -1)[:, flat]
 
 
+def reference_gate(flag, flat):
+    """acr/result_parser.py:124-145 at batch > 1: which frames' rows take their cross-hand prior.
+    flag [B,2] bool, flat [B,2] int64 (y*64+x) -> bool [B]."""
+    B = flag.shape[0]
+    gate = torch.zeros(B, dtype=torch.bool)
+    l_ids = [b for b in range(B) if flag[b, 0]]            # l_batch_ids (:93), ascending
+    r_ids = [b for b in range(B) if flag[b, 1]]
+    # detection_flag holds a False for a side without any hit in the batch (:106,116); :131 wants every entry True
+    if not l_ids or not r_ids:
+        return gate
+    both = [b for b in l_ids if b in r_ids]                # all_hand_valid_batch_ids (:126-128)
+    if not both:
+        return gate
+    # determine_coeff (:42-47): l_centers[0] vs r_centers[0] = the first detected left / right center of the batch
+    fl, fr = int(flat[l_ids[0], 0]), int(flat[r_ids[0], 1])
+    diff = torch.sqrt(torch.tensor(float((fl // MAP - fr // MAP) ** 2 + (fl % MAP - fr % MAP) ** 2)))
+    if diff > 32:
+        return gate                                        # both priors := 0 for the whole batch
+    for b in both:
+        gate[b] = True
+    return gate
+
+
 @torch.no_grad()
-def decode(maps):
+def decode(maps, batch_semantics='frame'):
     """maps: head dict (l/r_params_maps, l/r_center_map, l/r_prior_maps).
+    batch_semantics: 'frame' (below) | 'reference' (the prior decided batch-wide by reference_gate).
     Returns per-frame, per-hand slots (hand 0 = left, 1 = right), all float32/np:
       flag [B,2] bool, flat_ind [B,2] int64, score [B,2], params_pred [B,2,109],
       cam [B,2,3], poses [B,2,48], betas [B,2,10]
@@ -100,17 +124,23 @@ def decode(maps):
     flat = torch.stack([ind['l'], ind['r']], 1)
     flat = torch.where(flag, flat, torch.zeros_like(flat))
     pred = torch.zeros(B, 2, 109)
+    gate = reference_gate(flag, flat) if batch_semantics == 'reference' else None
     for b in range(B):
         l = sample(maps['l_params_maps'], b, flat[b, 0]).clone()
         r = sample(maps['r_params_maps'], b, flat[b, 1]).clone()
-        if flag[b, 0] and flag[b, 1]:
-            # cross prior (acr/result_parser.py:131-145) + determine_coeff (:42-47): centers as (y,x)
-            ly, lx = flat[b, 0] // MAP, flat[b, 0] % MAP
-            ry, rx = flat[b, 1] // MAP, flat[b, 1] % MAP
-            diff = torch.sqrt(((ly - ry).float()) ** 2 + ((lx - rx).float()) ** 2)
-            if not diff > 32:
-                l[3:] += sample(maps['l_prior_maps'], b, flat[b, 1])
-                r[3:] += sample(maps['r_prior_maps'], b, flat[b, 0])
+        if gate is not None:
+            use = bool(gate[b])
+        else:
+            use = False
+            if flag[b, 0] and flag[b, 1]:
+                # cross prior (acr/result_parser.py:131-145) + determine_coeff (:42-47): centers as (y,x)
+                ly, lx = flat[b, 0] // MAP, flat[b, 0] % MAP
+                ry, rx = flat[b, 1] // MAP, flat[b, 1] % MAP
+                diff = torch.sqrt(((ly - ry).float()) ** 2 + ((lx - rx).float()) ** 2)
+                use = not diff > 32
+        if use:
+            l[3:] += sample(maps['l_prior_maps'], b, flat[b, 1])
+            r[3:] += sample(maps['r_prior_maps'], b, flat[b, 0])
         pred[b, 0], pred[b, 1] = l, r
     flatp = pred.reshape(B * 2, 109)
     cam = flatp[:, :3]
@@ -136,3 +166,23 @@ def slots_to_rows(slots):
     rows['detection_flag'] = np.concatenate([slots['flag'][:, 0], slots['flag'][:, 1]], 0)
     rows['flat_ind'] = np.concatenate([slots['flat_ind'][:, 0], slots['flat_ind'][:, 1]], 0)
     return rows
+
+
+def slots_to_rows_batch(slots):
+    """Per-frame slots of a batch -> the reference's rows (acr/result_parser.py:102-120,166-183): all left rows of the
+    frames with a left hand (ascending), then the right rows; a side without any hit in the WHOLE batch keeps one
+    placeholder row (frame 0, pixel 0, flag False).  Also returns the frame of every row (reorganize_idx at
+    batch_ids = arange)."""
+    B = slots['flag'].shape[0]
+    rows = {k: [] for k in ('params_pred', 'cam', 'poses', 'betas', 'detection_flag', 'flat_ind', 'frame', 'hand_type')}
+    for h in (0, 1):
+        ids = [b for b in range(B) if slots['flag'][b, h]]
+        det = bool(ids)
+        for b in (ids or [0]):
+            for k in ('params_pred', 'cam', 'poses', 'betas'):
+                rows[k].append(slots[k][b, h])
+            rows['detection_flag'].append(det)
+            rows['flat_ind'].append(slots['flat_ind'][b, h] if det else 0)
+            rows['frame'].append(b)
+            rows['hand_type'].append(h)
+    return {k: np.asarray(v) for k, v in rows.items()}

@@ -38,6 +38,27 @@ def decode_maps(name):
     return m
 
 
+# Batches of the cases above: what the reference's parse_maps does with MIXED detection states in one
+# batch - the prior gated on every flag of the batch (acr/result_parser.py:131), determine_coeff deciding from row 0 of each
+# side's list (:42-47), whole-batch placeholder rows (:102-120).  tests/golden/make_golden_batch.py -> decode_batches.npz
+DECODE_BATCHES = {
+    'b2_both_leftonly': ('both_near', 'left_only'),                       # as per frame: prior in frame 0
+    'b2_far_near': ('both_far', 'both_near'),                             # row 0 is far apart: NO prior anywhere (frame 1 differs)
+    'b2_near_far': ('both_near', 'both_far'),                             # row 0 is near: prior everywhere (frame 1 differs)
+    'b2_leftonly_dist32': ('left_only', 'both_dist32'),                   # row 0 of the two sides come from different frames: 37.8 px -> none
+    'b3_rightonly_near_none': ('right_only', 'both_near', 'none'),        # l row 0 = frame 1, r row 0 = frame 0: 54 px -> none
+    'b4_no_right_at_all': ('left_only', 'below_thresh', 'none', 'left_only'),   # right placeholder row: flag False, no prior
+    'b4_mixed': ('both_near', 'none', 'right_only', 'both_far'),          # prior in frames 0 AND 3
+    'b2_none_none': ('none', 'none'),                                     # two placeholder rows
+}
+
+
+def decode_batch_maps(name):
+    """Head-map dict (float32, NCHW, B = len(members)) of a decode batch: the members' maps, concatenated."""
+    ms = [decode_maps(m) for m in DECODE_BATCHES[name]]
+    return {k: np.concatenate([m[k] for m in ms], 0) for k in ms[0]}
+
+
 def hash_name(name):
     h = 0
     for ch in name:

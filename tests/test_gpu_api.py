@@ -101,6 +101,79 @@ def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
     assert acr2(np.ascontiguousarray(frames2[0][:, :, ::-1]), 'n.jpg') == {'n.jpg': {}}
 
 
+def test_forward_batch_on_a_program_without_point_heads(synth_sd, mano_tables, frames2):
+    """acr.main.ACR.forward_batch defaults to point_heads=True, but packer.lower only emits the point-heads ops
+    for fp32 HRNet-W32 programs - a 16-bit program has none and acrmi_set_option(ACRMI_OPT_POINT_HEADS, 1) would fail.
+    Engine.set_point_heads now falls back to the dense heads (same results) and says so."""
+    a = pkg('config').parse_args(['--model_precision', 'fp16'])
+    acr = pkg('acr.main').ACR(args_set=a, state_dict=synth_sd, mano_tables=mano_tables, max_batch=2)
+    eng = acr.model.engine(2)
+    assert not eng.has_point_heads and eng.set_point_heads(True) is False
+    batch = acr.forward_batch(torch.from_numpy(frames2), ['a', 'b'])                      # default point_heads=True
+    dense = acr.forward_batch(torch.from_numpy(frames2), ['a', 'b'], point_heads=False)
+    g = golden('e2e_batch1.npz')
+    assert len(batch['a']) == 2 and len(batch['b']) == 2
+    for path in ('a', 'b'):
+        for hp, hd in zip(batch[path], dense[path]):
+            assert np.array_equal(hp['verts'], hd['verts'])
+    # the 16-bit contract against the reference's fp32 frames: millimetres, not the fp32 bar (DESIGN.md section 3)
+    assert np.abs(batch['a'][0]['verts'].astype(np.float32) - g['f0_verts'][0]).max() < 5e-3
+    # the fp32 engine of the other tests does carry them
+    acr32 = pkg('acr.main').ACR(state_dict=synth_sd, mano_tables=mano_tables, max_batch=2)
+    assert acr32.model.engine(2).has_point_heads
+
+
+@pytest.mark.parametrize('name', list(cases.DECODE_BATCHES))
+def test_result_parser_reference_batch_semantics(name):
+    """ResultParser(batch_semantics='reference').parse on device maps of a batch > 1 with mixed detection states returns
+    the rows the real reference returns (tests/golden/decode_batches.npz, captured by make_golden_batch.py): prior gated on
+    every flag of the batch, determine_coeff from row 0 of each side's list, whole-batch placeholder rows
+    (acr/result_parser.py:42-47,102-131).  The default per-frame mode differs where the fixture says it must."""
+    g = golden('decode_batches.npz')
+    rp = pkg('acr.result_parser')
+    maps = cases.decode_batch_maps(name)
+    B = maps['l_center_map'].shape[0]
+    res = {}
+    for mode in ('reference', 'frame'):
+        outputs = {k: torch.from_numpy(v).cuda() for k, v in maps.items()}
+        meta = {'batch_ids': torch.arange(B), 'offsets': torch.zeros(B, 10), 'imgpath': ['f%d' % b for b in range(B)]}
+        out, meta = rp.ResultParser(batch_semantics=mode).parse(outputs, meta, {})
+        res[mode] = out['params_pred'].cpu().numpy()
+        if mode == 'frame':
+            continue
+        np.testing.assert_array_equal(out['detection_flag'].cpu().numpy(), g[name + '_detection_flag'])
+        np.testing.assert_array_equal(out['reorganize_idx'].cpu().numpy(), g[name + '_reorganize_idx'])
+        np.testing.assert_array_equal(out['output_hand_type'].cpu().numpy(), g[name + '_hand_type'])
+        np.testing.assert_allclose(res[mode], g[name + '_params_pred'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out['params_dict']['cam'].cpu().numpy(), g[name + '_cam'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out['params_dict']['poses'].cpu().numpy(), g[name + '_poses'], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(out['params_dict']['betas'].cpu().numpy(), g[name + '_betas'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(out['l_centers_pred'].cpu().numpy(), g[name + '_l_centers_pred'])
+        np.testing.assert_array_equal(out['r_centers_pred'].cpu().numpy(), g[name + '_r_centers_pred'])
+    differs = np.abs(res['frame'] - res['reference']).max() > 1e-3
+    assert differs == (name in ('b2_far_near', 'b2_near_far', 'b2_leftonly_dist32', 'b3_rightonly_near_none', 'b4_mixed')), name
+
+
+def test_model_forward_reference_batch_semantics(synth_sd, frames2):
+    """acr.model.ACR(batch_semantics='reference').forward at batch 2 goes through the gated second decode: on the two
+    synthetic frames (both hands in both frames) the batch-wide gate equals the per-frame one unless the frames' center
+    distances fall on different sides of 32 px - either way the rows must equal a hand-gated decode of the same maps."""
+    rp = pkg('acr.result_parser')
+    m = pkg('acr.model').ACR(device=0, max_batch=2, batch_semantics='reference').eval()
+    m.load_state_dict(synth_sd)
+    meta = {'image': torch.from_numpy(frames2), 'offsets': torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]] * 2),
+            'batch_ids': torch.arange(2), 'imgpath': ['a', 'b']}
+    out = m.cuda()(meta, mode='parsing', calc_loss=False)
+    eng = m.engine(2)
+    first = eng.decode(2)
+    gate = rp.reference_prior_gate(first)
+    want = rp.rows_from_slots(eng.decode(2, prior_gate=gate))
+    assert torch.equal(out['params_pred'], want['params_pred']) and out['params_pred'].shape[0] == 4
+    forced_off = rp.rows_from_slots(eng.decode(2, prior_gate=torch.zeros(2, dtype=torch.int32)))
+    if int(gate.sum()) > 0:
+        assert (forced_off['params_pred'] - want['params_pred']).abs().max().item() > 1e-4     # the gate is live
+
+
 def test_cam_trans_kernel_matches_reference_least_squares():
     """§8f-3: acrmi_cam_trans == the reference's closed-form least squares (acr/utils.py:430-472; restated in numpy
     fp64 in oracle/smooth.py and pinned against the reference's cam_trans in test_oracle_pinned)."""

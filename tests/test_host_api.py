@@ -184,3 +184,59 @@ def test_state_dict_surface_without_gpu(synth_sd):
     assert torch.equal(m.state_dict()['l_final_layers.2.2.bias'], synth_sd['l_final_layers.2.2.bias'])
     with pytest.raises(ValueError):
         m.load_state_dict({'backbone.conv1.weight': torch.zeros(3, 3)})
+
+
+def test_splitk_slices_are_whole_32_channel_chunks():
+    """split-K slices must satisfy the kernel's Cin % 32 == 0 per slice - 576 / 640 input channels used to become
+    8 slices of 72 / 80 channels, a program acrmi_set_program rejects."""
+    packer = pkg('packer')
+    for cin in (128, 256, 384, 512, 576, 640, 1024):
+        s = packer.splitk_slices(3, 1, cin, 256, 1, 16, 16, False)
+        assert 1 <= s <= 8 and cin % s == 0 and (s == 1 or (cin // s) % 32 == 0), (cin, s)
+    assert packer.splitk_slices(3, 1, 256, 256, 1, 16, 16, False) == 4          # HRNet branch 3 unchanged
+    assert packer.splitk_slices(3, 1, 128, 128, 1, 32, 32, False) == 2          # branch 2 unchanged
+    assert packer.splitk_slices(3, 1, 576, 256, 1, 16, 16, False) == 6
+    assert packer.splitk_slices(3, 1, 640, 256, 1, 16, 16, False) == 5
+
+
+@pytest.mark.parametrize('name', list(cases.DECODE_BATCHES))
+def test_reference_batch_semantics_host_logic(name):
+    """ResultParser(batch_semantics='reference'): result_parser.reference_prior_gate decides from a first decode's flags /
+    centers what the reference decides batch-wide (acr/result_parser.py:42-47,131), rows_from_slots re-packs the second
+    decode - both checked here on CPU against the real reference's rows (decode_batches.npz), with the oracle standing in
+    for the decode kernel."""
+    rp = pkg('acr.result_parser')
+    S = pkg('_lib')
+    g = golden('decode_batches.npz')
+    maps = {k: torch.from_numpy(v) for k, v in cases.decode_batch_maps(name).items()}
+
+    def as_slots(d):
+        B = d['flag'].shape[0]
+        sl = torch.zeros(B, 2, S.SLOT)
+        sl[:, :, S.SLOT_FLAG] = torch.from_numpy(d['flag'].astype(np.float32))
+        sl[:, :, S.SLOT_FLATIND] = torch.from_numpy(d['flat_ind'].astype(np.float32))
+        sl[:, :, S.SLOT_SCORE] = torch.from_numpy(d['score'])
+        sl[:, :, S.SLOT_CAM:S.SLOT_CAM + 3] = torch.from_numpy(d['cam'])
+        sl[:, :, S.SLOT_POSES:S.SLOT_POSES + 48] = torch.from_numpy(d['poses'])
+        sl[:, :, S.SLOT_BETAS:S.SLOT_BETAS + 10] = torch.from_numpy(d['betas'])
+        sl[:, :, S.SLOT_PARAMS:S.SLOT_PARAMS + 109] = torch.from_numpy(d['params_pred'])
+        return sl
+    first = as_slots(odec.decode(maps))                                   # pass 1: per-frame rule (what acrmi_decode does)
+    gate = rp.reference_prior_gate(first)
+    want = odec.reference_gate(torch.from_numpy(odec.decode(maps)['flag']), torch.from_numpy(odec.decode(maps)['flat_ind']))
+    np.testing.assert_array_equal(gate.numpy().astype(bool), want.numpy())
+    second = as_slots(odec.decode(maps, batch_semantics='reference'))     # pass 2: the gated decode
+    B = second.shape[0]
+    meta = {'batch_ids': torch.arange(B), 'imgpath': ['f%d' % b for b in range(B)]}
+    out = rp.rows_from_slots(second, meta)
+    np.testing.assert_array_equal(out['detection_flag'].numpy(), g[name + '_detection_flag'])
+    np.testing.assert_array_equal(out['reorganize_idx'].numpy(), g[name + '_reorganize_idx'])
+    np.testing.assert_array_equal(out['output_hand_type'].numpy(), g[name + '_hand_type'])
+    assert [int(out['left_hand_num']), int(out['right_hand_num'])] == g[name + '_hand_nums'].tolist()
+    np.testing.assert_allclose(out['params_pred'].numpy(), g[name + '_params_pred'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out['params_dict']['poses'].numpy(), g[name + '_poses'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(out['l_centers_pred'].numpy(), g[name + '_l_centers_pred'])
+    np.testing.assert_array_equal(out['r_centers_pred'].numpy(), g[name + '_r_centers_pred'])
+    assert list(meta['imgpath']) == ['f%d' % b for b in g[name + '_reorganize_idx']]
+    with pytest.raises(ValueError):
+        rp.ResultParser(batch_semantics='whole-batch')

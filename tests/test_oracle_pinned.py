@@ -69,6 +69,30 @@ def test_decode_cases_match_reference(name):
     assert rows['flat_ind'][0] == lc[1] * 64 + lc[0] and rows['flat_ind'][1] == rc[1] * 64 + rc[0]
 
 
+@pytest.mark.parametrize('name', list(cases.DECODE_BATCHES))
+def test_decode_batches_match_reference(name):
+    """The reference's parse_maps on a batch > 1 with mixed detection states (tests/golden/make_golden_batch.py): the
+    oracle's batch_semantics='reference' mode reproduces its rows; the per-frame mode differs exactly in the batches
+    the fixture was built to separate."""
+    g = golden('decode_batches.npz')
+    maps = {k: torch.from_numpy(v) for k, v in cases.decode_batch_maps(name).items()}
+    rows = odec.slots_to_rows_batch(odec.decode(maps, batch_semantics='reference'))
+    np.testing.assert_array_equal(rows['detection_flag'], g[name + '_detection_flag'].astype(bool))
+    np.testing.assert_array_equal(rows['frame'], g[name + '_reorganize_idx'])
+    np.testing.assert_array_equal(rows['hand_type'], g[name + '_hand_type'])
+    _close(rows['params_pred'], g[name + '_params_pred'], 1e-6, 1e-6)
+    _close(rows['cam'], g[name + '_cam'], 1e-6, 1e-6)
+    _close(rows['betas'], g[name + '_betas'], 1e-6, 1e-6)
+    _close(rows['poses'], g[name + '_poses'], 1e-5, 1e-5)
+    L = int(g[name + '_hand_nums'][0])
+    centers = np.concatenate([g[name + '_l_centers_pred'], g[name + '_r_centers_pred']], 0)
+    np.testing.assert_array_equal(rows['flat_ind'], centers[:, 1] * 64 + centers[:, 0])
+    assert len(g[name + '_l_centers_pred']) == L
+    per_frame = odec.slots_to_rows_batch(odec.decode(maps))
+    differs = np.abs(per_frame['params_pred'] - g[name + '_params_pred']).max() > 1e-3
+    assert differs == (name in ('b2_far_near', 'b2_near_far', 'b2_leftonly_dist32', 'b3_rightonly_near_none', 'b4_mixed')), name
+
+
 def test_rot6d_kat_match_reference():
     g = golden('rot6d_kat.npz')
     x6 = torch.from_numpy(g['x6'])
