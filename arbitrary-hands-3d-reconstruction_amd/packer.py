@@ -469,6 +469,19 @@ class Program(object):
             self.ops[-1].w_off2 = self.blob.add(bias_map)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
                                     'winograd_f2x4_3x3')[algo] + ('_splitk%d' % slices if slices > 1 else '')
+        # what bench.py prints next to the PMC traffic: the kernel family launch_conv picks for this op (conv_mfma.hip /
+        # conv_wino24b.inc wino24b_ok) and the op's ALGORITHMIC HBM bytes per frame - input slice + output (+ residual)
+        # once, in their storage types
+        ng = len(wb_list)
+        esz = lambda b: 4 if self.dtype_of(b) == DT_F32 else 2
+        fam = ('conv_ws2_kernel', 'conv_wino_kernel', 'conv_wino2_kernel', 'conv_wino3_kernel', 'conv_wino24_kernel')[algo]
+        if algo == 4 and cin % 32 == 0 and cin >= 64 and cout % 64 == 0 and ho % 8 == 0 and wo % 32 == 0:
+            fam = 'conv_wino24b_kernel'
+        if self.dt != DT_F32:
+            fam = 'conv_h16_kernel'
+        self.op_info[-1]['kernel'] = fam
+        self.op_info[-1]['bytes'] = float(h * w_ * cin * ng * esz(src) + ho * wo * (cout if slices > 1 else cout * ng) * esz(out) *
+                                          (2 if res is not None else 1))
         if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
             self.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for (w, b) in wb_list]
         return out

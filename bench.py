@@ -30,9 +30,9 @@ PKG = 'arbitrary-hands-3d-reconstruction_amd'
 
 GFLOP_PER_FRAME = 102.1          # BASELINE.md §3 / SURVEY.md §8d (2*MAC, direct conv + bmm + linear)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
-DOMINANT = 'conv_wino24_kernel + conv_wino3_kernel + conv_wino2_kernel (3x3 stride-1 convolutions: Winograd F(2x4,3x3) / F(2x2,3x3) on fp32 MFMA)'
+DOMINANT = 'conv_wino24b_kernel + conv_wino3_kernel + conv_wino2_kernel (3x3 stride-1 convolutions: Winograd F(2x4,3x3) / F(2x2,3x3) on fp32 MFMA)'
 MFMA_REDUCTION = {'winograd_f2x2_3x3': 2.25, 'winograd_f2x2_3x3_lds': 2.25, 'winograd_f23x': 1.5, 'winograd_f2x4_3x3': 3.0}   # algorithmic MACs per executed MFMA MAC
-PROFILE_TAGS = ('r03', 'r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
+PROFILE_TAGS = ('r04', 'r03', 'r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
 
 
 def pkg(sub):
@@ -185,6 +185,114 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
                    'accumulate / bias / residual / ReLU, one rounding per layer; stem, head exits, attention pooling, '
                    'decode, MANO fp32.  parity is against the FP32 oracle.')
     return res
+
+
+def config3_video_stream(sd, tables, steps, warmup, local_rank, B=32, H=1080, W=1920):
+    """BASELINE.json configs[3], one GPU's shard (batch 128 over 4 GPUs = 32 frames per GPU), END TO END from host memory
+    (reference acr/utils.py:1315-1337 -> network): 1080p BGR uint8 frames in PINNED host memory -> H2D on a
+    copy stream into one of two device staging buffers -> acrmi_preprocess (BGR->RGB, white square pad, OpenCV's fixed-point
+    INTER_CUBIC to 512x512) -> acrmi_forward with the pad geometry in `offsets` (two contexts in turn).  The copy of batch
+    k+1 overlaps pre-processing + network of batch k.  Also timed alone, on the same buffers: the H2D copy, the
+    pre-processing kernel (HIP events), the network on resident 512x512 frames - `bound_by` names the slowest stage.
+    Parity of this path: tests/test_gpu_api.py::test_raw_1080p_batch_end_to_end (all 32 frames vs the oracle)."""
+    import ctypes as C
+    ops, L = pkg('ops'), pkg('_lib')
+    dev = torch.device('cuda', local_rank)
+    host = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, H, W, 3), dtype=np.uint8)).pin_memory()
+    stage = [torch.empty(B, H, W, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+    pool = pkg('engine').EnginePool(local_rank, n=2)
+    pool.load_state_dict(sd, max_batch=B, lanes=1)
+    pool.load_mano(tables)
+    raw = C.c_void_p()
+    L.check(L.lib().acrmi_stream_create(local_rank, C.byref(raw)))       # a plain HIP stream (not torch's pool of 32)
+    copy_stream = torch.cuda.ExternalStream(raw.value, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    vsets = [None, None]      # (the contexts allocate slots / verts / joints / verts_camed / pj2d / pj2d_org per batch)
+    frame_bytes = H * W * 3
+
+    def run(n):
+        copied = [torch.cuda.Event() for _ in range(2)]
+        consumed = [None, None]
+        pend = []
+        for i in range(n):
+            j = i % 2
+            if consumed[j] is not None:
+                copy_stream.wait_event(consumed[j])             # the staging buffer's previous batch has been pre-processed
+            with torch.cuda.stream(copy_stream):
+                stage[j].copy_(host, non_blocking=True)
+                copied[j].record(copy_stream)
+            cur.wait_event(copied[j])
+            rgb, offs = ops.preprocess(stage[j])
+            consumed[j] = torch.cuda.Event()
+            consumed[j].record(cur)
+            pend.append(pool.submit(rgb, offsets=offs, project=True, out=vsets[j]))
+            while len(pend) > 1:
+                pool.collect(pend.pop(0))
+        for t in pend:
+            pool.collect(t)
+    try:
+        run(max(2, warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # ---- the stages alone
+        with torch.cuda.stream(copy_stream):
+            stage[0].copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(copy_stream):
+            for i in range(steps):
+                stage[i % 2].copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        dt_h2d = (time.perf_counter() - t1) / steps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rgb, offs = ops.preprocess(stage[0])
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            rgb, offs = ops.preprocess(stage[0])
+        e1.record()
+        torch.cuda.synchronize()
+        pre_ms = e0.elapsed_time(e1) / steps
+
+        def net(n):
+            pend = []
+            for i in range(n):
+                pend.append(pool.submit(rgb, offsets=offs, project=True, out=vsets[i % 2]))
+                while len(pend) > 1:
+                    pool.collect(pend.pop(0))
+            for t in pend:
+                pool.collect(t)
+        net(2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        net(steps)
+        torch.cuda.synchronize()
+        dt_net = (time.perf_counter() - t2) / steps
+    finally:
+        pool.close()
+        # the pinned block and the staging buffers go FIRST: torch's host allocator records an event on every stream a
+        # pinned block was used on when the block is freed - on a stream that has already been destroyed that is a
+        # segfault (seen here).  (Rebinding the names also clears the cells the closures above hold.)
+        host = stage = rgb = offs = None
+        torch.cuda.synchronize()
+        L.lib().acrmi_stream_destroy(raw)
+    pre_bytes = B * (frame_bytes + 512 * 512 * 3)
+    stages = {'h2d': B / dt_h2d, 'preprocess': B / (pre_ms * 1e-3), 'network': B / dt_net}
+    return {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+            'frames_per_gpu': B, 'frame': '%dx%d BGR uint8 (%.2f MB), pinned host memory' % (W, H, frame_bytes / 1e6),
+            'h2d_gb_per_s': round(B * frame_bytes / dt_h2d / 1e9, 2), 'h2d_ms_per_batch': round(dt_h2d * 1e3, 3),
+            'preprocess_ms_per_frame': round(pre_ms / B, 4), 'preprocess_ms_per_batch': round(pre_ms, 3),
+            'preprocess_roofline': {'bound': 'hbm', 'achieved': round(pre_bytes / (pre_ms * 1e-3) / 1e9, 1), 'peak': 8000.0,
+                                    'unit': 'GB/s', 'frac': round(pre_bytes / (pre_ms * 1e-3) / 1e9 / 8000.0, 4),
+                                    'algorithmic_bytes_per_frame': frame_bytes + 512 * 512 * 3},
+            'network_fps_resident_frames': round(B / dt_net, 2),
+            'stage_fps_alone': {k: round(v, 1) for k, v in stages.items()},
+            'bound_by': min(stages, key=stages.get),
+            'pipeline': 'H2D (copy stream, 2 staging buffers) || preprocess + forward (2 contexts in turn); fp32 HRNet-W32',
+            'pcie_inclusive': True}
 
 
 def other_configs(tables, steps, warmup, local_rank):
@@ -502,7 +610,7 @@ def main():
             if traffic is None and os.path.exists(tpath):
                 with open(tpath) as f:
                     kk = json.load(f)['kernels']
-                    traffic = round((kk.get('conv_wino24_kernel') or kk.get('conv_wino2_kernel') or {}).get('hbm_bytes_per_launch', 0)) or None
+                    traffic = round((kk.get('conv_wino24b_kernel') or kk.get('conv_wino24_kernel') or kk.get('conv_wino2_kernel') or {}).get('hbm_bytes_per_launch', 0)) or None
                 traffic_src = 'profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)' % tag
             bpath = os.path.join(ROOT, 'profiles', '%s_pmc_mfma.json' % tag)
             if busy is None and os.path.exists(bpath):
@@ -591,6 +699,19 @@ def main():
                 out['roofline']['traffic_kernel'] = top
                 out['roofline']['traffic'] = t2 or out['roofline']['traffic']
                 out['roofline']['traffic_source'] = live['source'] if t2 else out['roofline']['traffic_source']
+                # algorithmic bytes per launch of every conv family (packer: input slice + output + residual once, x frames),
+                # so that wasted re-reads are a printed ratio, not an inference
+                alg = {}
+                for p in prof:
+                    if p['kind'] == L.OP_CONV and p.get('kernel'):
+                        a = alg.setdefault(p['kernel'], [0.0, 0])
+                        a[0] += p['bytes'] * B
+                        a[1] += 1
+                for k, v in live['traffic'].items():
+                    if k in alg and alg[k][1]:
+                        v['algorithmic_bytes_per_launch'] = round(alg[k][0] / alg[k][1])
+                        v['launches_per_step'] = alg[k][1]
+                        v['traffic_over_algorithmic'] = round(v['hbm_bytes_per_launch'] / max(1.0, alg[k][0] / alg[k][1]), 3)
                 out['roofline']['traffic_per_kernel'] = live['traffic']
                 out['roofline']['mfma_busy_pmc'] = dict(live['mfma_busy'], source=live['source'])
             else:
@@ -601,6 +722,11 @@ def main():
                 pool = None
             out['reduced_precision'] = reduced_precision(sd, tables, frames, B, args.steps, args.warmup, oracle, local_rank)
             out['other_configs'] = other_configs(tables, args.steps, args.warmup, local_rank)
+            try:
+                out['other_configs']['configs[3] 1080p stream, per-GPU shard (32 frames), host memory -> meshes'] = \
+                    config3_video_stream(sd, tables, args.steps, args.warmup, local_rank)
+            except Exception as exc:      # (a host that cannot pin 200 MB must not cost the headline line)
+                out['other_configs']['configs[3]'] = {'error': repr(exc)}
         line = json.dumps(out)
     else:
         line = None
