@@ -224,6 +224,17 @@ WINOGRAD_LDS = True
 WINOGRAD_24 = __import__('os').environ.get('ACRMI_WINO24', '1') != '0'
 
 
+def wino24b_width(cin, cout, ho, wo):
+    """Item width of conv_wino24b_kernel for a 3x3 stride-1 conv (csrc/conv_wino24b.inc wino24b_ok): 32, 16 or 0 = not taken."""
+    if not (cin % 32 == 0 and cin >= 64 and cout % 64 == 0):
+        return 0
+    if ho % 8 == 0 and wo % 32 == 0:
+        return 32
+    if ho % 16 == 0 and wo % 16 == 0:
+        return 16
+    return 0
+
+
 def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, wino24=None):
     """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3).
     wino24: None = WINOGRAD_24; False keeps the F(2x2,3x3) kernels for the layers F(2x4,3x3) would take (small batches:
@@ -233,9 +244,13 @@ def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, 
     if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
             and not per_frame_bias):
         return 3
-    if (WINOGRAD_2D and (WINOGRAD_24 if wino24 is None else wino24) and cin > 32 and cout != 33 and wo % 32 == 0
-            and ho % 8 == 0):
-        return 4
+    if WINOGRAD_2D and (WINOGRAD_24 if wino24 is None else wino24) and cin > 32 and cout != 33:
+        if wo % 32 == 0 and ho % 8 == 0:
+            return 4
+        # maps narrower than 32 pixels (HRNet branch 3, 16 x 16): the four-wave frame's 16x16-pixel items
+        # (conv_wino24b_kernel<2, 16>); conv_wino24_kernel itself would waste half of its 32 slots there
+        if wino24b_width(cin, cout, ho, wo) == 16:
+            return 4
     return 2 if WINOGRAD_2D else 1
 
 
@@ -475,7 +490,7 @@ class Program(object):
         ng = len(wb_list)
         esz = lambda b: 4 if self.dtype_of(b) == DT_F32 else 2
         fam = ('conv_ws2_kernel', 'conv_wino_kernel', 'conv_wino2_kernel', 'conv_wino3_kernel', 'conv_wino24_kernel')[algo]
-        if algo == 4 and cin % 32 == 0 and cin >= 64 and cout % 64 == 0 and ho % 8 == 0 and wo % 32 == 0:
+        if algo == 4 and wino24b_width(cin, cout, ho, wo):
             fam = 'conv_wino24b_kernel'
         if self.dt != DT_F32:
             fam = 'conv_h16_kernel'

@@ -184,6 +184,9 @@ WINO24B_CASES = [
     (2, 96, 128, 8, 32, 1, False, 2, False),       # three chunks, one tile per frame (all four borders), no ReLU, map residual
     (2, 64, 64, 16, 96, 1, False, 0, True),        # interior tile columns, per-frame bias rows
     (1, 64, 192, 24, 64, 1, True, 1, True),        # three n-blocks
+    (3, 256, 256, 16, 16, 1, True, 1, False),      # HRNet branch 3: the 16x16-pixel items, one per frame and n-block, 8 chunks
+    (2, 64, 128, 32, 16, 1, True, 0, False),       # ... two tiles per frame (top / bottom borders differ)
+    (2, 64, 64, 16, 48, 1, False, 2, True),        # ... three tile columns: an interior one; map residual + frame bias
 ]
 
 

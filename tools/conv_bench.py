@@ -110,7 +110,7 @@ def main():
         wino = 0
         if k == 3 and stride == 1:
             wino = 2 if (args.wino2 or args.wino3 or args.wino24) else (1 if args.wino else 0)
-            if args.wino24 and cing > 32 and coutg != 33:
+            if args.wino24 and cing > 32 and coutg != 33 and (W % 32 == 0 or packer.wino24b_width(cing, coutg, H, W) == 16):
                 wino = 4
         if wino and args.wino3 and groups == 1 and cin <= 32 and cout == 32:
             wino = 3
