@@ -563,7 +563,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
           (op.res_buf >= 0 && (bufs[op.res_buf].h != ho || bufs[op.res_buf].w != wo)))
         return fail(c, ACRMI_EINVAL, "op %d: output/residual buffer geometry does not match the convolution", i);
       const long long n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
-      if (algo == 4 && op.cin <= 32) return fail(c, ACRMI_EINVAL, "op %d: algo 4 needs Cin > 32 (two 32-channel chunks per item)", i);
+      if (algo == 4 && (op.cin < 32 || (op.cin == 32 && (op.cout % 32 || ho % 8 || wo % 32))))      // (Cin = 32: conv_wino24b_kernel only)
+        return fail(c, ACRMI_EINVAL, "op %d: algo 4 needs Cin > 32, or Cin = 32 with Cout %% 32 = 0 on a map of 8x32-pixel tiles", i);
       const long long taps = algo == 4 ? 24 : (algo >= 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize));
       const long long ksteps = idt ? (op.cin + 15) / 16 : (op.cin + 7) / 8;      // 1 KiB weight fragments per tap and n-tile
       const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ksteps * n_tiles * 256;
@@ -1089,7 +1090,8 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   if (algo == 3 && (groups != 1 || cin > 32 || cout != 32 || bias_frame_stride != 0 || H % 8 || W % 16 || out_cs % 4 ||
                     out_coff % 4 || (res && (res_cs % 4 || res_coff % 4))))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 3 needs groups 1, Cin <= 32, Cout = 32, H %% 8 == 0, W %% 16 == 0");
-  if (algo == 4 && cin <= 32) return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 4 needs Cin > 32");
+  if (algo == 4 && (cin < 32 || (cin == 32 && (cout % 32 || H % 8 || W % 32))))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 4 needs Cin > 32 (or Cin = 32, Cout %% 32 = 0 on a map of 8x32-pixel tiles)");
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: only 3x3 and 1x1 at stride 1 / 2 are implemented (got k%d s%d)", ksize, stride);
   if (in_cs % 4 || in_coff % 4 || (groups > 1 && cin % 4))

@@ -565,10 +565,9 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.splitk && a.algo != 2) return hipErrorInvalidValue;
   if (a.algo == 4)                              // F(2x4,3x3): weights packed with 4x6 taps; four-wave frame where it applies
-    switch (wino24b_ok(a)) {
-      case 32: return launch_wino24b_32(a, s);
-      case 16: return launch_wino24b_16(a, s);
-      default: return launch_wino24(a, s);
+    {
+      const int tw = wino24b_ok(a);
+      return tw ? launch_wino24b(a, tw, s) : launch_wino24(a, s);
     }
   if (a.algo == 3) return launch_wino3(a, s);   // F(2x2,3x3), Cin <= 32, Cout = 32: weights packed for LDS residency
   if (a.algo == 2) {   // Winograd F(2x2,3x3): 3x3 stride 1 only, weights packed with 16 taps

@@ -226,11 +226,11 @@ WINOGRAD_24 = __import__('os').environ.get('ACRMI_WINO24', '1') != '0'
 
 def wino24b_width(cin, cout, ho, wo):
     """Item width of conv_wino24b_kernel for a 3x3 stride-1 conv (csrc/conv_wino24b.inc wino24b_ok): 32, 16 or 0 = not taken."""
-    if not (cin % 32 == 0 and cin >= 64 and cout % 64 == 0):
+    if not (cin % 32 == 0 and cin >= 32 and cout % 32 == 0):
         return 0
     if ho % 8 == 0 and wo % 32 == 0:
-        return 32
-    if ho % 16 == 0 and wo % 16 == 0:
+        return 32                                     # two n-tiles per wave when Cout % 64 == 0, else one
+    if ho % 16 == 0 and wo % 16 == 0 and cin >= 64 and cout % 64 == 0:
         return 16
     return 0
 
@@ -244,12 +244,12 @@ def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, 
     if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
             and not per_frame_bias):
         return 3
-    if WINOGRAD_2D and (WINOGRAD_24 if wino24 is None else wino24) and cin > 32 and cout != 33:
-        if wo % 32 == 0 and ho % 8 == 0:
+    if WINOGRAD_2D and (WINOGRAD_24 if wino24 is None else wino24) and cout != 33:
+        if cin > 32 and wo % 32 == 0 and ho % 8 == 0:
             return 4
-        # maps narrower than 32 pixels (HRNet branch 3, 16 x 16): the four-wave frame's 16x16-pixel items
-        # (conv_wino24b_kernel<2, 16>); conv_wino24_kernel itself would waste half of its 32 slots there
-        if wino24b_width(cin, cout, ho, wo) == 16:
+        # what only the four-wave frame takes: maps narrower than 32 pixels (HRNet branch 3, 16 x 16: conv_wino24_kernel would
+        # waste half of its 32 slots there) and single-chunk items (Cin = 32 with Cout a multiple of 64: the contact conv)
+        if wino24b_width(cin, cout, ho, wo) and (cin > 32 or cout % 64 == 0):
             return 4
     return 2 if WINOGRAD_2D else 1
 

@@ -31,6 +31,8 @@ SHAPES = [
     ('segm 64->33 3x3 @256', 64, 33, 256, 256, 3, 1, 1, False),
     ('segm 33->33 3x3 @256', 33, 33, 256, 256, 3, 1, 1, False),
     ('contact 34->256 3x3 @128', 34, 256, 128, 128, 3, 1, 1, False),
+    ('contact 32->256 3x3 @128 (+map)', 32, 256, 128, 128, 3, 1, 1, False),
+    ('segm 256->32 3x3 @128', 256, 32, 128, 128, 3, 1, 1, False),
     ('l1 64->256 1x1 @128', 64, 256, 128, 128, 1, 1, 1, True),
     ('l1 256->64 1x1 @128', 256, 64, 128, 128, 1, 1, 1, False),
     ('s2 64->64 3x3s2 @256', 64, 64, 256, 256, 3, 2, 1, False),
@@ -110,8 +112,8 @@ def main():
         wino = 0
         if k == 3 and stride == 1:
             wino = 2 if (args.wino2 or args.wino3 or args.wino24) else (1 if args.wino else 0)
-            if args.wino24 and cing > 32 and coutg != 33 and (W % 32 == 0 or packer.wino24b_width(cing, coutg, H, W) == 16):
-                wino = 4
+            if args.wino24 and coutg != 33 and ((cing > 32 and W % 32 == 0) or packer.wino24b_width(cing, coutg, H, W)):
+                wino = 4      # (incl. Cin = 32 shapes: the four-wave frame's single-chunk kernels, also where the program keeps conv_wino3)
         if wino and args.wino3 and groups == 1 and cin <= 32 and cout == 32:
             wino = 3
             packed = [packer.pack_wino3(w.astype(np.float64), np.zeros(coutg, np.float32))]
