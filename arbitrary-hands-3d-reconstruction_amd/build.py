@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libacrmi.so')
-SOURCES = ['acrmi.hip', 'conv_mfma.hip', 'conv_h16.hip', 'elementwise.hip', 'heads.hip', 'mano.hip', 'stem.hip', 'stem7.hip', 'pair1x1.hip']
+SOURCES = ['acrmi.hip', 'acrmi_program.hip', 'acrmi_ops.hip', 'acrmi_comm.hip', 'conv_mfma.hip', 'conv_h16.hip', 'elementwise.hip', 'heads.hip', 'mano.hip', 'stem.hip', 'stem7.hip', 'pair1x1.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 
 

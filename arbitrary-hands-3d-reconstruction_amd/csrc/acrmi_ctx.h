@@ -1,0 +1,121 @@
+// Internal header of libacrmi.so: the context, the error / device-guard helpers and what the translation units of the C
+// ABI share.  acrmi.hip = context life cycle, options, the fused entry points; acrmi_program.hip = program validation,
+// dependency schedule and replay (one stream / parallel lanes); acrmi_ops.hip = the stand-alone operators;
+// acrmi_comm.hip = RCCL.
+#pragma once
+#include "../../include/acrmi.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace acrmi;
+
+// ---- op dependencies and stream lanes ----------------------------------------------------------------
+constexpr int MAX_LANES = 8;
+// ACRMI_OPT_LANES = 0: measured on MI355X (tools/lanes_check.py) - batch 1: 6.97 ms on one stream, 4.63 on four;
+// batch 32: 23.2 / 22.5 / 22.2 ms on one / two / four; batch 64: 46.9 ms on one, 45.6 on two (the second lane fills the
+// tails and pipeline fills of the first), 45.8 on three
+constexpr int AUTO_LANES_SMALL = 4, AUTO_LANES_LARGE = 2, AUTO_SMALL_BATCH = 32;
+struct Schedule {
+  std::vector<int> order;               // active op indices, program order (a topological order)
+  std::vector<std::vector<int>> deps;   // per op: earlier ops it must wait for (RAW / WAR / WAW on buffer ids)
+  std::vector<char> leaf;               // per op: no later op depends on it
+  // multi-stream form (ACRMI_OPT_LANES): lane per op, events of other lanes' ops to wait for, event to record
+  int n_lanes = 0;
+  std::vector<int> lane;
+  std::vector<std::vector<int>> wait;
+  std::vector<char> signal;
+};
+struct acrmi_ctx {
+  int device = 0;
+  std::string err;
+  float* weights = nullptr;
+  size_t n_weights = 0;
+  std::vector<acrmi_buffer_desc> bufs;
+  std::vector<float*> buf_ptr;
+  std::vector<acrmi_op> ops;
+  acrmi_head_layout heads{};
+  bool have_program = false;
+  int max_batch = 0;
+  float* att_ws = nullptr;      // attention-pool workspace
+  size_t att_ws_floats = 0;
+  int* picks = nullptr;         // point heads: decoded centers per frame [max_batch,4]
+  bool point_heads = false;     // ACRMI_OPT_POINT_HEADS
+  Schedule sched[2][2];         // [point][0: small batches / 1: large batches]
+  // ACRMI_OPT_LANES: independent chains of the program on parallel HIP streams (lane 0 = the caller's stream)
+  int want_lanes = 0;           // 0 = by batch size (AUTO_LANES_*)
+  // ACRMI_OPT_LANE_PLAN: lane per op from MEASURED op times (acrmi_profile_ops at a small batch stores them here), small-
+  // batch schedules only; empty = the structural heuristic
+  bool lane_plan = false;       // (explicit: Engine.tune_lanes / the host switches it on after profiling)
+  std::vector<float> op_ms[2];  // [point]: per-op milliseconds of the last small-batch profile
+  hipStream_t lanes[MAX_LANES] = {};
+  hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {};
+  std::vector<hipEvent_t> op_ev;
+  // split-K convolutions (ACRMI_CONV_SPLITK): partial tiles + arrival counters, one set per lane (ops of one lane are
+  // stream-ordered; ops of different lanes may overlap)
+  float* split_ws[MAX_LANES] = {};
+  unsigned* split_cnt[MAX_LANES] = {};
+  size_t split_ws_floats = 0, split_counters = 0;
+  ManoTables mano[2]{};
+  bool have_mano[2] = {false, false};
+  float* mano_allocs[2][9] = {};   // 6 fp32 tables + 3 f16 copies per side
+  bool mano_f16 = false;           // ACRMI_OPT_MANO_FP16
+  // options the reference reads from its config (acr/config.py): centermap_conf_thresh (acr/result_parser.py:241),
+  // align_idx / mano_mesh_root_align (acr/mano_wrapper.py:19-33), -t temporal_optimization + smooth_coeff (acr/main.py:45-47)
+  float conf_thresh = 0.35f;
+  int center_idx = 9;           // < 0: no root alignment
+  bool temporal = false;
+  float smooth_coeff = 4.0f;
+  float* smooth_state = nullptr;   // [2][3][64] floats + 2 ints (One-Euro state of one video stream)
+  // multi-GPU: RCCL communicator created by acrmi_comm_init
+  void* comm = nullptr;
+  int comm_ranks = 0;
+};
+
+// Every entry point runs on the context's device and leaves the caller's current device as it found it (a process
+// may hold contexts on several GPUs).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// last error of calls without a context (acrmi_create, the stand-alone operators)
+extern std::string g_err;
+int fail(acrmi_ctx* c, int code, const char* fmt, ...);
+#define ON_DEVICE(c)                                                                                   \
+  DeviceGuard guard_((c)->device);                                                                     \
+  if (guard_.err != hipSuccess) return fail(c, ACRMI_EHIP, "hipSetDevice(%d): %s", (c)->device, hipGetErrorString(guard_.err))
+#define HIPCHK(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(c, ACRMI_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+
+// ---- shared between the translation units ------------------------------------------------------------------------
+void free_program(acrmi_ctx* c);                       // acrmi_program.hip
+void comm_destroy(acrmi_ctx* c);                       // acrmi_comm.hip
+int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s, int lane = 0);
+bool op_active(const acrmi_op& op, bool point);
+void build_schedule(acrmi_ctx* c, bool point, bool large);
+int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point);
