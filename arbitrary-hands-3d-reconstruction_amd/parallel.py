@@ -33,6 +33,16 @@ def shard_range(n_frames, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def padded_shard(n_frames, rank, world):
+    """Shard of a global batch that need not divide by the world size: every rank runs ceil(n / world) frames so that the
+    all-gather has equal counts.  Returns (lo, hi, per): this rank's REAL frames are [lo, hi) (possibly none), it runs
+    `per` frames (the caller fills per - (hi - lo) of them with padding), and the gathered result keeps rows
+    [r * per, r * per + (hi_r - lo_r)) of every rank r."""
+    per = (n_frames + world - 1) // world
+    lo = min(rank * per, n_frames)
+    return lo, min(lo + per, n_frames), per
+
+
 def alloc_result(n_frames, device):
     """One flat buffer [slots | verts | joints] so that a shard is gathered with ONE collective."""
     flat = torch.empty(n_frames * 2 * PER_HAND, dtype=torch.float32, device=device)
@@ -103,6 +113,29 @@ class ShardedRunner(object):
         self._comm_stream = None
         self._pending = {}
 
+    def _make_comm_stream(self):
+        """The side stream the gathers run on.  With an Engine at hand it is a plain HIP stream of the library
+        (acrmi_stream_create) seen by torch as an external stream: torch.cuda.Stream() instantiates torch's whole pool of 32
+        streams per priority, after which the few streams in use share hardware queues (DESIGN.md "Parallel lanes")."""
+        if self.engine is None:
+            return torch.cuda.Stream(self.device)
+        import ctypes as C
+        from . import _lib
+        raw = C.c_void_p()
+        _lib.check(_lib.lib().acrmi_stream_create(self.device.index or 0, C.byref(raw)))
+        self._raw_comm_stream = raw
+        return torch.cuda.ExternalStream(raw.value, device=self.device)
+
+    def close(self):
+        """Releases the library stream the gathers ran on (after every ticket has been collected)."""
+        raw = getattr(self, '_raw_comm_stream', None)
+        if raw is not None:
+            torch.cuda.synchronize(self.device)
+            from . import _lib
+            self._comm_stream = None
+            _lib.lib().acrmi_stream_destroy(raw)
+            self._raw_comm_stream = None
+
     def _set(self, n_local, turn):
         world = dist.get_world_size(self.group)
         if n_local not in self._buf:
@@ -126,7 +159,7 @@ class ShardedRunner(object):
         ticket = {'turn': turn, 'n_local': n_local, 'event': None, 'work': None}
         if self.device.type == 'cuda':
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(self.device)
+                self._comm_stream = self._make_comm_stream()
             # local_forward ran on the current stream - or, when it returns an event (engine.EnginePool: the batch runs
             # on one of the pool's own streams), that event marks its end
             done = ret if isinstance(ret, torch.cuda.Event) else torch.cuda.Event()
@@ -159,7 +192,20 @@ class ShardedRunner(object):
         return self.collect(self.submit(frames_local))
 
     def forward_global(self, frames_global):
-        """Strong-scaling entry: every rank sees the global batch and takes its contiguous shard."""
+        """Strong-scaling entry: every rank sees the global batch and takes its contiguous shard.  A batch that does not
+        divide by the world size is padded per rank to ceil(n / world) frames (copies of the shard's last frame; a rank
+        whose shard is empty runs copies of the batch's last frame) and the padding rows are dropped after the gather:
+        the result is exactly the n frames, in order."""
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
-        lo, hi = shard_range(frames_global.shape[0], rank, world)
-        return self.forward_local(frames_global[lo:hi])
+        n = frames_global.shape[0]
+        if n % world == 0:
+            lo, hi = shard_range(n, rank, world)
+            return self.forward_local(frames_global[lo:hi])
+        lo, hi, per = padded_shard(n, rank, world)
+        real = frames_global[lo:hi] if hi > lo else frames_global[n - 1:n]
+        pad = per - real.shape[0]
+        local = torch.cat([real, real[-1:].expand(pad, *real.shape[1:])], 0) if pad else real
+        out = self.forward_local(local.contiguous())
+        keep = torch.cat([torch.arange(r * per, r * per + (padded_shard(n, r, world)[1] - padded_shard(n, r, world)[0]))
+                          for r in range(world)]).to(next(iter(out.values())).device)
+        return {k: v.index_select(0, keep) for k, v in out.items()}

@@ -527,7 +527,16 @@ def main():
         os.environ.setdefault('WORLD_SIZE', '1')
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # ACRMI_GATHER=c: the data-path collective is the library's own acrmi_allgather (RCCL through the C ABI), so the process
+        # group only carries the unique id, the barriers and the timing reduction - over gloo.  With backend nccl the process
+        # would hold TWO RCCL communicators (torch's, created by its first collective, and the library's): measured at world
+        # size 1 (tools/allgather_probe.py) a side-stream all-gather next to a running batch then costs +11.4 ms per batch
+        # (46.8 vs 35.4 ms) against +0.2 ms with the library's communicator alone - what r2's "slow C transport" was.
+        c_transport = os.environ.get('ACRMI_GATHER') == 'c'
+        if c_transport:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     synth, parallel = pkg('synth'), pkg('parallel')
     B = args.batch
@@ -542,6 +551,10 @@ def main():
     eng.load_state_dict(sd, max_batch=B, precision=args.precision)
     eng.load_mano(tables)
     eng.set_lanes(args.lanes)
+    if use_dist and os.environ.get('ACRMI_GATHER') == 'c':
+        # the C-ABI transport's own RCCL communicator is created BEFORE the pool's streams exist: a communicator created
+        # later lands its internal stream on a hardware queue one of the contexts already uses (r2: 1367 vs 1553 frames/s)
+        parallel.init_engine_comm(eng)
     frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False)).cuda()   # resident in HBM
     pool = None
     if npipe > 1:
@@ -580,7 +593,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
@@ -641,6 +654,7 @@ def main():
                'dtype': {'fp32': 'f32', 'fp16': 'f16 storage / f32 accumulate (NOT the headline precision)', 'bf16': 'bf16 storage / f32 accumulate (NOT the headline precision)'}[args.precision], 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
                'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, %s' % args.precision,
                           'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
+                          'gather': (('rccl all-gather of result slots per batch, transport ' + runner.transport) if runner is not None else 'none (one rank)'),
                           'contexts_in_turn': npipe,
                           'gflop_per_frame': GFLOP_PER_FRAME},
                'roofline': roofline}

@@ -86,6 +86,13 @@ def _worker(rank, world, port, q):
         same = all(torch.equal(got[k], got2[k]) and torch.equal(got[k], r0[k]) for k in got)
         # (the stand-in's torch-CPU math differs by ~1e-7 with a frame's position in the batch: allclose, not equal)
         same = same and third and torch.allclose(r1['slots'], flipped, rtol=0, atol=2e-6)
+        # a global batch that does NOT divide by the world size (5 frames on 2 ranks: 3 + 2, rank 1 pads one frame): the
+        # padding rows are dropped after the gather, the result is the 5 frames in order
+        odd = runner.forward_global(frames[:5])
+        same = same and all(v.shape[0] == 5 for v in odd.values())
+        same = same and all(torch.allclose(odd[k], got[k][:5], rtol=0, atol=2e-6) for k in got)
+        one = runner.forward_global(frames[:1])            # fewer frames than ranks: rank 1's shard is empty
+        same = same and all(v.shape[0] == 1 and torch.allclose(v, got[k][:1], rtol=0, atol=2e-6) for k, v in one.items())
         q.put((rank, {k: v.numpy() for k, v in got.items()}, same))
     finally:
         dist.destroy_process_group()
@@ -203,6 +210,18 @@ def test_bench_step_loop_over_gloo(mano_tables):
         assert ok
         for k in ('slots', 'verts', 'joints'):
             np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-6)
+
+
+def test_padded_shard_covers_every_frame_once():
+    parallel = pkg('parallel')
+    for n in (1, 2, 5, 7, 64, 65, 127):
+        for world in (1, 2, 3, 4, 8):
+            rows = []
+            for r in range(world):
+                lo, hi, per = parallel.padded_shard(n, r, world)
+                assert per == -(-n // world) and 0 <= hi - lo <= per
+                rows += list(range(lo, hi))
+            assert rows == list(range(n)), (n, world)
 
 
 def test_shard_range_and_buffer_layout():
