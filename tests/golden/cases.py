@@ -53,6 +53,10 @@ DECODE_BATCHES = {
 }
 
 
+# the whole reference (model.forward + MANOWrapper) on a batch > 1: name -> (checkpoint seed of STATE_CHECKPOINTS, frames)
+E2E_BATCHES = {'both_b4': (10, 4), 'left_only_b3': (3, 3), 'none_b2': (7, 2)}
+
+
 def decode_batch_maps(name):
     """Head-map dict (float32, NCHW, B = len(members)) of a decode batch: the members' maps, concatenated."""
     ms = [decode_maps(m) for m in DECODE_BATCHES[name]]

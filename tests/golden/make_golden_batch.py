@@ -51,6 +51,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'decode_batches.npz'), **out)
     print('decode_batches.npz', os.path.getsize(os.path.join(HERE, 'decode_batches.npz')) // 1024, 'KB')
 
+    # ---- the whole reference at batch > 1: model.forward (backbone, heads, parse_maps on the batch) + MANOWrapper ------------
+    model = ref_model.ACR().eval()
+    wrapper = ref_wrapper.MANOWrapper()
+    e2e = {}
+    for name, (seed, B) in cases.E2E_BATCHES.items():
+        model.load_state_dict(synth.make_state_dict(seed=seed), strict=True)
+        frames = torch.from_numpy(synth.make_frames(B, seed=cases.STATE_FRAME_SEED))
+        meta = {'image': frames, 'offsets': torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]] * B),
+                'batch_ids': torch.arange(B), 'imgpath': ['b%d' % b for b in range(B)]}
+        with torch.no_grad():
+            o = model(meta, mode='parsing', calc_loss=False)
+            keys = ['params_pred', 'detection_flag', 'l_centers_pred', 'r_centers_pred', 'output_hand_type', 'reorganize_idx']
+            if o['detection_flag'].sum() > 0:
+                o = wrapper(o, o['meta_data'])
+                keys += ['verts', 'j3d', 'pj2d', 'cam_trans']
+        for k in keys:
+            e2e['%s_%s' % (name, k)] = o[k].numpy()
+        for k in ('cam', 'poses', 'betas'):
+            e2e['%s_%s' % (name, k)] = o['params_dict'][k].numpy()
+        e2e[name + '_hand_nums'] = np.array([int(o['left_hand_num']), int(o['right_hand_num'])])
+        print('e2e', name, 'flags', e2e[name + '_detection_flag'].tolist(), 'rows of frames', e2e[name + '_reorganize_idx'].tolist(),
+              'l centers', e2e[name + '_l_centers_pred'].tolist(), 'r centers', e2e[name + '_r_centers_pred'].tolist())
+    np.savez_compressed(os.path.join(HERE, 'e2e_batches.npz'), **e2e)
+    print('e2e_batches.npz', os.path.getsize(os.path.join(HERE, 'e2e_batches.npz')) // 1024, 'KB')
+
 
 if __name__ == '__main__':
     main()

@@ -174,6 +174,38 @@ def test_model_forward_reference_batch_semantics(synth_sd, frames2):
         assert (forced_off['params_pred'] - want['params_pred']).abs().max().item() > 1e-4     # the gate is live
 
 
+@pytest.mark.parametrize('name', list(cases.E2E_BATCHES))
+def test_model_forward_at_batch_gt_1_matches_the_reference(name, mano_tables):
+    """acr.model.ACR(batch_semantics='reference').forward(meta_data) + MANOWrapper on a batch of 4 / 3 / 2 frames returns what
+    the REAL reference's model.forward + MANOWrapper returned on the same batch (tests/golden/e2e_batches.npz): rows, their
+    order (all left rows, then the right rows), the whole-batch placeholder row, reorganize_idx, meshes."""
+    g = golden('e2e_batches.npz')
+    seed, B = cases.E2E_BATCHES[name]
+    m = pkg('acr.model').ACR(device=0, max_batch=B, batch_semantics='reference').eval()
+    m.load_state_dict(pkg('synth').make_state_dict(seed=seed))
+    m.cuda()
+    wrapper = pkg('acr.mano_wrapper').MANOWrapper(tables=mano_tables, engine=m.engine())
+    frames = torch.from_numpy(pkg('synth').make_frames(B, seed=cases.STATE_FRAME_SEED))
+    meta = {'image': frames, 'offsets': torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]] * B), 'batch_ids': torch.arange(B),
+            'imgpath': ['b%d' % b for b in range(B)]}
+    out = m(meta, mode='parsing', calc_loss=False)
+    np.testing.assert_array_equal(out['detection_flag'].cpu().numpy(), g[name + '_detection_flag'])
+    np.testing.assert_array_equal(out['reorganize_idx'].cpu().numpy(), g[name + '_reorganize_idx'])
+    np.testing.assert_array_equal(out['output_hand_type'].cpu().numpy(), g[name + '_output_hand_type'])
+    np.testing.assert_array_equal(out['l_centers_pred'].cpu().numpy(), g[name + '_l_centers_pred'])
+    np.testing.assert_array_equal(out['r_centers_pred'].cpu().numpy(), g[name + '_r_centers_pred'])
+    assert [int(out['left_hand_num']), int(out['right_hand_num'])] == g[name + '_hand_nums'].tolist()
+    np.testing.assert_allclose(out['params_pred'].cpu().numpy(), g[name + '_params_pred'], 2e-4, 2e-4)
+    assert list(out['meta_data']['imgpath']) == ['b%d' % b for b in g[name + '_reorganize_idx']]
+    if out['detection_flag'].sum() > 0:                   # acr/main.py:96
+        out = wrapper(out, out['meta_data'])
+        for k in ('verts', 'j3d'):
+            assert np.abs(out[k].cpu().numpy() - g[name + '_' + k]).max() < 1e-4, k
+        np.testing.assert_allclose(out['pj2d'].cpu().numpy(), g[name + '_pj2d'], 1e-3, 2e-4)
+        np.testing.assert_allclose(out['cam_trans'].cpu().numpy(), g[name + '_cam_trans'], 5e-3, 5e-3)
+    m.engine().close()
+
+
 def test_cam_trans_kernel_matches_reference_least_squares():
     """§8f-3: acrmi_cam_trans == the reference's closed-form least squares (acr/utils.py:430-472; restated in numpy
     fp64 in oracle/smooth.py and pinned against the reference's cam_trans in test_oracle_pinned)."""

@@ -189,6 +189,35 @@ def test_network_states_match_reference(name, mano_tables):
         assert np.hypot(*(lc - rc).astype(float)) <= 32
 
 
+@pytest.mark.parametrize('name', list(cases.E2E_BATCHES))
+def test_network_batches_match_reference(name, mano_tables):
+    """The WHOLE reference at batch > 1 (model.forward on 4 / 3 / 2 frames + MANOWrapper, tests/golden/make_golden_batch.py ->
+    e2e_batches.npz): the oracle with batch_semantics='reference' returns its rows in its order - all left rows of the
+    batch, then the right rows, one placeholder row for a side without any hit in the batch."""
+    g = golden('e2e_batches.npz')
+    torch.set_num_threads(8)
+    seed, B = cases.E2E_BATCHES[name]
+    sd = pkg('synth').make_state_dict(seed=seed)
+    frames = torch.from_numpy(pkg('synth').make_frames(B, seed=cases.STATE_FRAME_SEED))
+    with torch.no_grad():
+        heads = acr_net.network(sd, frames)
+    rows = odec.slots_to_rows_batch(odec.decode(heads, batch_semantics='reference'))
+    np.testing.assert_array_equal(rows['detection_flag'], g[name + '_detection_flag'].astype(bool))
+    np.testing.assert_array_equal(rows['frame'], g[name + '_reorganize_idx'])
+    np.testing.assert_array_equal(rows['hand_type'], g[name + '_output_hand_type'])
+    centers = np.concatenate([g[name + '_l_centers_pred'], g[name + '_r_centers_pred']], 0)
+    np.testing.assert_array_equal(rows['flat_ind'], centers[:, 1] * 64 + centers[:, 0])
+    _close(rows['params_pred'], g[name + '_params_pred'], 2e-4, 2e-4)
+    if name == 'none_b2':
+        assert name + '_verts' not in g.files
+        return
+    L = int(g[name + '_hand_nums'][0])
+    vl, jl, _ = omano.mano_forward(_tables(mano_tables, 'l'), 'left', rows['poses'][:L], rows['betas'][:L])
+    vr, jr, _ = omano.mano_forward(_tables(mano_tables, 'r'), 'right', rows['poses'][L:], rows['betas'][L:])
+    assert np.abs(np.concatenate([vl, vr]) - g[name + '_verts']).max() < 2e-5
+    assert np.abs(np.concatenate([jl, jr]) - g[name + '_j3d']).max() < 2e-5
+
+
 @pytest.mark.parametrize('name', list(cases.INTERIOR_CASES))
 def test_interior_centers_match_reference(name, mano_tables):
     """centers >= 9 px from every border of the map (planted with synth.plant_center_peaks; every other
