@@ -73,12 +73,19 @@ class ManoLayer(object):
     def __init__(self, center_idx=None, flat_hand_mean=True, ncomps=6, side='right', mano_root='model_data/mano/',
                  use_pca=True, root_rot_mode='axisang', joint_rot_mode='axisang', robust_rot=False, tables=None,
                  device=0):
-        if use_pca or root_rot_mode != 'axisang' or joint_rot_mode != 'axisang':
-            raise ValueError('only use_pca=False with axis-angle rotations is implemented '
-                             '(the configuration acr/mano_wrapper.py:17-35 uses)')
+        if root_rot_mode != 'axisang':
+            # (the reference itself cannot run this mode: mano/manolayer.py:148-150 calls a module `rot6d` it never imports)
+            raise ValueError("root_rot_mode=%r: only 'axisang' is implemented" % (root_rot_mode,))
+        if not use_pca and joint_rot_mode != 'axisang':
+            raise ValueError("joint_rot_mode=%r without use_pca (rotation-matrix poses through batch_rotprojs, "
+                             "mano/manolayer.py:152-163) is not implemented" % (joint_rot_mode,))
         if side not in ('left', 'right'):
             raise ValueError('side must be "left" or "right"')
-        self.center_idx, self.side, self.use_pca, self.ncomps = center_idx, side, False, 45
+        if use_pca and not 0 < ncomps <= 45:
+            raise ValueError('ncomps must be 1..45')
+        # use_pca: the pose coefficients are PCA coordinates, th_selected_comps = the first ncomps rows of hands_components
+        # (mano/manolayer.py:47-50,89-93,124-129); ACR's own wrapper uses use_pca=False (acr/mano_wrapper.py:17-35)
+        self.center_idx, self.side, self.use_pca, self.ncomps = center_idx, side, bool(use_pca), (ncomps if use_pca else 45)
         self.flat_hand_mean, self.rot, self.robust_rot = flat_hand_mean, 3, robust_rot
         self.root_rot_mode, self.joint_rot_mode = root_rot_mode, joint_rot_mode
         if tables is None:
@@ -96,6 +103,9 @@ class ManoLayer(object):
         self.th_hands_mean = torch.from_numpy(hm.copy()).unsqueeze(0)
         if 'hands_components' in t:
             self.th_comps = torch.from_numpy(t['hands_components'].astype(np.float32).copy())
+            self.th_selected_comps = self.th_comps[:self.ncomps].clone()
+        elif use_pca:
+            raise ValueError('use_pca=True needs the hands_components table')
         kt = t.get('kintree_table')
         self.kintree_parents = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14] if kt is None else list(kt[0].tolist())
         self._device = device
@@ -129,18 +139,32 @@ class ManoLayer(object):
     def forward(self, th_pose_coeffs, th_betas=torch.zeros(1), th_trans=torch.zeros(1), root_palm=torch.Tensor([0]),
                 share_betas=torch.Tensor([0])):
         """-> (verts [N,778,3], joints [N,21,3], center_joint [N,1,3]) in metres (mano/manolayer.py:269-276)."""
-        if bool(root_palm):
-            raise ValueError('root_palm=True is not implemented')
         if self._dirty or self._engine is None:
             self.sync(self._engine)
         eng = self._engine
         N = th_pose_coeffs.shape[0]
+        if self.use_pca:      # PCA coordinates -> the 45 axis-angle values (the kernel adds th_hands_mean, :132-135)
+            c = th_pose_coeffs.detach().float().cpu()
+            th_pose_coeffs = torch.cat([c[:, :3], c[:, 3:3 + self.ncomps].mm(self.th_selected_comps)], 1)
         if th_betas is None or th_betas.numel() == 1:
             th_betas = self.th_betas.expand(N, 10)
         elif bool(share_betas):
             th_betas = th_betas.mean(0, keepdim=True).expand(N, 10)
         use_trans = not (th_trans is None or bool(torch.norm(th_trans.float()) == 0))
         side = torch.full((N,), 0 if self.side == 'left' else 1, dtype=torch.int32)
+        if bool(root_palm):
+            # mano/manolayer.py:249-251: the wrist joint is replaced by the palm = mean of vertices 95 and 22 BEFORE the
+            # root alignment, so the kernel runs unaligned and the alignment (:258-266) happens here
+            verts, joints, _, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=None)
+            joints = joints.clone()
+            joints[:, 0] = (verts[:, 95] + verts[:, 22]) / 2
+            if use_trans:
+                t = th_trans.to(verts.device).float().unsqueeze(1)
+                return verts + t, joints + t, t
+            if self.center_idx is None:
+                return verts, joints, None
+            center = joints[:, self.center_idx].unsqueeze(1).clone()
+            return verts - center, joints - center, center
         cidx = None if use_trans else self.center_idx
         verts, joints, center, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=cidx)
         if use_trans:

@@ -328,10 +328,31 @@ def other_configs(tables, steps, warmup, local_rank):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         gflop = sum(i['flops'] for i in pool.engines[0].program['op_info'] if i.get('mode', 0) != pkg('_lib').MODE_POINT) / 1e9
+        # what the 16-bit program costs in metres: the same checkpoint as an fp32 program of this library on 8 structured
+        # frames (no reference network exists for these backbones, so the fp32 program - whose kernels and lowering are the
+        # reference-pinned ones - is the yardstick; tests/test_gpu_h16.py checks both against the build's own oracle)
+        L = pkg('_lib')
+        pf = torch.from_numpy(synth.make_frames(8, seed=3)).cuda()
+        o16 = pool.engines[0].forward(pf)
+        torch.cuda.synchronize()
+        o16 = {k: v.cpu().numpy() for k, v in o16.items()}
+        pool.close()
+        e32 = pkg('engine').Engine(local_rank)
+        e32.load_state_dict(sd, max_batch=8, precision='fp32')
+        e32.load_mano(tables)
+        o32 = {k: v.cpu().numpy() for k, v in e32.forward(pf).items()}
+        e32.close()
+        f16, f32_ = o16['slots'][..., L.SLOT_FLAG] > 0.5, o32['slots'][..., L.SLOT_FLAG] > 0.5
+        same = (f16 == f32_) & (~f32_ | (o16['slots'][..., L.SLOT_FLATIND] == o32['slots'][..., L.SLOT_FLATIND]))
+        use = same & f32_
+        dv = np.linalg.norm(o16['verts'] - o32['verts'], axis=-1)[use]
         res[name] = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
                      'gflop_per_frame': round(gflop, 1), 'tflops': round(B * steps * gflop / dt / 1e3, 1),
-                     'parity': 'no reference network: HIP vs the build\'s own oracle in tests/test_gpu_h16.py'}
-        pool.close()
+                     'gflop_per_frame_source': 'sum of the lowered program\'s algorithmic conv / pooling FLOPs (packer op_info), dense heads',
+                     'parity': {'max_vertex_l2_m': float(dv.max()) if dv.size else None, 'hands_compared': int(use.sum()),
+                                'decisions_differing': int((~same).sum()), 'frames': 8,
+                                'against': 'the SAME checkpoint as an fp32 program of this library (no reference network exists for '
+                                           'this backbone); per-op parity of both vs the build\'s own oracle: tests/test_gpu_h16.py'}}
     return res
 
 

@@ -57,6 +57,27 @@ DECODE_BATCHES = {
 E2E_BATCHES = {'both_b4': (10, 4), 'left_only_b3': (3, 3), 'none_b2': (7, 2)}
 
 
+# ManoLayer beyond the wrapper's configuration (VERDICT r3 "missing" 5): constructor options + forward options, inputs seeded
+# name -> (ctor kwargs, forward options, n, seed)
+MANO_OPTION_CASES = {
+    'pca6_flat_right_c9': (dict(use_pca=True, ncomps=6, flat_hand_mean=True, side='right', center_idx=9), {}, 4, 21),
+    'pca12_mean_left_nocenter': (dict(use_pca=True, ncomps=12, flat_hand_mean=False, side='left', center_idx=None), {}, 3, 22),
+    'palm_right_c0': (dict(use_pca=False, flat_hand_mean=False, side='right', center_idx=0), dict(root_palm=True), 3, 23),
+    'palm_trans_left': (dict(use_pca=False, flat_hand_mean=True, side='left', center_idx=9), dict(root_palm=True, trans=True), 2, 24),
+    'pca45_share_betas': (dict(use_pca=True, ncomps=45, flat_hand_mean=False, side='right', center_idx=9), dict(share_betas=True), 4, 25),
+}
+
+
+def mano_option_inputs(name):
+    kw, opt, n, seed = MANO_OPTION_CASES[name]
+    g = rng(1300 + seed)
+    nc = kw['ncomps'] if kw.get('use_pca') else 45
+    poses = g.normal(0, 0.5, (n, 3 + nc)).astype(np.float32)
+    betas = g.normal(0, 1.0, (n, 10)).astype(np.float32)
+    trans = g.normal(0, 0.2, (n, 3)).astype(np.float32) if opt.get('trans') else None
+    return poses, betas, trans
+
+
 def decode_batch_maps(name):
     """Head-map dict (float32, NCHW, B = len(members)) of a decode batch: the members' maps, concatenated."""
     ms = [decode_maps(m) for m in DECODE_BATCHES[name]]

@@ -74,6 +74,25 @@ def main():
         print('e2e', name, 'flags', e2e[name + '_detection_flag'].tolist(), 'rows of frames', e2e[name + '_reorganize_idx'].tolist(),
               'l centers', e2e[name + '_l_centers_pred'].tolist(), 'r centers', e2e[name + '_r_centers_pred'].tolist())
     np.savez_compressed(os.path.join(HERE, 'e2e_batches.npz'), **e2e)
+
+    # ---- ManoLayer options the wrapper does not use: use_pca / ncomps, flat_hand_mean, root_palm, th_trans, share_betas ------
+    mo = {}
+    for name, (kw, opt, n, seed) in cases.MANO_OPTION_CASES.items():
+        layer = ref_manolayer.ManoLayer(mano_root='unused/', **kw)
+        poses, betas, trans = cases.mano_option_inputs(name)
+        args = dict(th_betas=torch.from_numpy(betas))
+        if trans is not None:
+            args['th_trans'] = torch.from_numpy(trans)
+        if opt.get('root_palm'):
+            args['root_palm'] = torch.Tensor([1])
+        if opt.get('share_betas'):
+            args['share_betas'] = torch.Tensor([1])
+        with torch.no_grad():
+            v, j, c = layer(torch.from_numpy(poses), **args)
+        mo[name + '_verts'], mo[name + '_joints'] = v.numpy(), j.numpy()
+        mo[name + '_center'] = c.numpy() if c is not None else np.zeros((0, 1, 3), np.float32)
+        print('mano option', name, 'verts absmax %.3f' % np.abs(mo[name + '_verts']).max())
+    np.savez_compressed(os.path.join(HERE, 'mano_options.npz'), **mo)
     print('e2e_batches.npz', os.path.getsize(os.path.join(HERE, 'e2e_batches.npz')) // 1024, 'KB')
 
 

@@ -72,9 +72,36 @@ def test_manolayer_surface(mano_tables):
     v0, j0, _ = lay(torch.zeros(0, 48), th_betas=torch.zeros(0, 10))
     assert v0.shape == (0, 778, 3)
     with pytest.raises(ValueError):
-        ML(side='right', use_pca=True, tables=mano_tables['right'])
+        ML(side='right', use_pca=False, root_rot_mode='rotmat', tables=mano_tables['right'])     # (broken in the reference too)
+    with pytest.raises(ValueError):
+        ML(side='right', use_pca=False, joint_rot_mode='rotmat', tables=mano_tables['right'])
     with pytest.raises(FileNotFoundError):
         ML(side='left', use_pca=False, mano_root='/nonexistent/')
+
+
+@pytest.mark.parametrize('name', list(cases.MANO_OPTION_CASES))
+def test_manolayer_options_match_reference(name, mano_tables):
+    """ManoLayer beyond acr/mano_wrapper.py's configuration - use_pca / ncomps, flat_hand_mean, root_palm, th_trans,
+    share_betas (mano/manolayer.py:13-22,104-160,249-276) - against the REAL reference's ManoLayer on the same synthetic
+    tables (tests/golden/mano_options.npz, make_golden_batch.py)."""
+    g = golden('mano_options.npz')
+    kw, opt, n, seed = cases.MANO_OPTION_CASES[name]
+    lay = pkg('mano.manolayer').ManoLayer(tables=mano_tables[kw['side']], **kw)
+    poses, betas, trans = cases.mano_option_inputs(name)
+    args = dict(th_betas=torch.from_numpy(betas))
+    if trans is not None:
+        args['th_trans'] = torch.from_numpy(trans)
+    if opt.get('root_palm'):
+        args['root_palm'] = torch.Tensor([1])
+    if opt.get('share_betas'):
+        args['share_betas'] = torch.Tensor([1])
+    v, j, c = lay(torch.from_numpy(poses), **args)
+    assert np.abs(v.cpu().numpy() - g[name + '_verts']).max() < 5e-6
+    assert np.abs(j.cpu().numpy() - g[name + '_joints']).max() < 5e-6
+    if g[name + '_center'].size:
+        assert np.abs(c.cpu().numpy() - g[name + '_center']).max() < 5e-6
+    else:
+        assert c is None
 
 
 def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
