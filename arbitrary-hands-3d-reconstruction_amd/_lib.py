@@ -49,7 +49,7 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias',
            'acrmi_buffer_dtype', 'acrmi_conv2d_h16', 'acrmi_conv2d_splitk', 'acrmi_conv2d_splitk_workspace',
-           'acrmi_decode_gated', 'acrmi_decode_maps_gated']
+           'acrmi_decode_gated', 'acrmi_decode_maps_gated', 'acrmi_share_weights']
 
 _lib = None
 
@@ -88,6 +88,7 @@ def lib():
     L.acrmi_decode.argtypes = [vp, i32, f32p, vp]
     L.acrmi_decode_maps.argtypes = [f32p, f32p, i32, f32p, f32p, i32, f32p, f32p, i32, i32, C.c_float, f32p, vp]
     L.acrmi_decode_gated.argtypes = [vp, i32, vp, f32p, vp]
+    L.acrmi_share_weights.argtypes = [vp, vp]
     L.acrmi_decode_maps_gated.argtypes = [f32p, f32p, i32, f32p, f32p, i32, f32p, f32p, i32, i32, C.c_float, vp, f32p, vp]
     L.acrmi_mano.argtypes = [vp, f32p, i32, f32p, i32, vp, i32, i32, f32p, f32p, f32p, f32p, i32, f32p, f32p, f32p,
                              f32p, vp]

@@ -14,6 +14,18 @@ int fail(acrmi_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
+// the blob is freed by the last context that holds it (contexts are single-threaded per the ABI; sharing contexts of one
+// pool are driven by one host thread)
+void release_weights(acrmi_ctx* c) {
+  if (c->weights_ref && --*c->weights_ref == 0) {
+    (void)hipFree(c->weights);
+    delete c->weights_ref;
+  }
+  c->weights = nullptr;
+  c->weights_ref = nullptr;
+  c->n_weights = 0;
+}
+
 extern "C" {
 
 int acrmi_version(void) { return ACRMI_VERSION; }
@@ -47,7 +59,7 @@ void acrmi_destroy(acrmi_ctx* c) {
     if (c->join_ev[l]) (void)hipEventDestroy(c->join_ev[l]);
   }
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
-  if (c->weights) (void)hipFree(c->weights);
+  release_weights(c);
   if (c->smooth_state) (void)hipFree(c->smooth_state);
   for (auto& side : c->mano_allocs)
     for (float* p : side)
@@ -58,11 +70,24 @@ void acrmi_destroy(acrmi_ctx* c) {
 int acrmi_load_weights(acrmi_ctx* c, const float* blob, size_t n) {
   if (!c || !blob || n == 0) return fail(c, ACRMI_EINVAL, "acrmi_load_weights: bad arguments");
   ON_DEVICE(c);
-  if (c->weights) (void)hipFree(c->weights);
-  c->weights = nullptr;
+  release_weights(c);
   HIPCHK(c, hipMalloc(&c->weights, n * sizeof(float)));
   HIPCHK(c, hipMemcpy(c->weights, blob, n * sizeof(float), hipMemcpyHostToDevice));
   c->n_weights = n;
+  c->weights_ref = new int(1);
+  return ACRMI_OK;
+}
+
+int acrmi_share_weights(acrmi_ctx* c, acrmi_ctx* donor) {
+  if (!c || !donor || c == donor) return fail(c, ACRMI_EINVAL, "acrmi_share_weights: bad arguments");
+  if (!donor->weights) return fail(c, ACRMI_ESTATE, "acrmi_share_weights: the donor holds no weights");
+  if (c->device != donor->device) return fail(c, ACRMI_EINVAL, "acrmi_share_weights: contexts on different devices (%d, %d)", c->device, donor->device);
+  ON_DEVICE(c);
+  release_weights(c);
+  c->weights = donor->weights;
+  c->n_weights = donor->n_weights;
+  c->weights_ref = donor->weights_ref;
+  ++*c->weights_ref;
   return ACRMI_OK;
 }
 

@@ -38,8 +38,9 @@ struct Schedule {
 struct acrmi_ctx {
   int device = 0;
   std::string err;
-  float* weights = nullptr;
+  float* weights = nullptr;     // the packed blob on the device - owned, or another context's (acrmi_share_weights)
   size_t n_weights = 0;
+  int* weights_ref = nullptr;   // host-side use count of `weights` shared by the contexts that hold it (null: no blob)
   std::vector<acrmi_buffer_desc> bufs;
   std::vector<float*> buf_ptr;
   std::vector<acrmi_op> ops;
@@ -114,6 +115,7 @@ int fail(acrmi_ctx* c, int code, const char* fmt, ...);
 
 // ---- shared between the translation units ------------------------------------------------------------------------
 void free_program(acrmi_ctx* c);                       // acrmi_program.hip
+void release_weights(acrmi_ctx* c);                    // acrmi.hip: drops this context's hold on its weight blob
 void comm_destroy(acrmi_ctx* c);                       // acrmi_comm.hip
 int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s, int lane = 0);
 bool op_active(const acrmi_op& op, bool point);

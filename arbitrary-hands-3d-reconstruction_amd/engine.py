@@ -68,11 +68,17 @@ class Engine(object):
                                        keep_all=keep_all, wino24=wino24, splitk=small if splitk == 'auto' else splitk),
                           max_batch)
 
-    def load_program(self, prog, max_batch=1):
+    def load_program(self, prog, max_batch=1, share_with=None):
         """A program lowered elsewhere (packer.lower, or another Engine's `program`): the same packed weights and op
-        list in this context - an EnginePool lowers the checkpoint once."""
-        blob = prog['blob']
-        _lib.check(self.L.acrmi_load_weights(self.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), self.ctx)
+        list in this context - an EnginePool lowers the checkpoint once.
+        share_with: an Engine of the same device that already holds THIS program: its device copy of the weight blob is
+        used instead of a second upload (acrmi_share_weights; 330 MB per context at HRNet-W32 fp32)."""
+        if share_with is not None and share_with is not self and share_with.program is prog and \
+                share_with.device == self.device:
+            _lib.check(self.L.acrmi_share_weights(self.ctx, share_with.ctx), self.ctx)
+        else:
+            blob = prog['blob']
+            _lib.check(self.L.acrmi_load_weights(self.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), self.ctx)
         self.program = prog
         self._set_program(max_batch)
 
@@ -444,9 +450,11 @@ class EnginePool(object):
                                                                        splitk=max_batch < 16)
         if prog is None:
             raise _lib.AcrmiError('no checkpoint loaded')
+        holder = next((e for e in self.engines if e.program is prog), None)      # a context that already holds the blob
         for e in self.engines:
             if e.program is not prog:
-                e.load_program(prog, max_batch)
+                e.load_program(prog, max_batch, share_with=holder)      # one device copy of the weights for the pool
+                holder = holder or e
             else:
                 e.ensure_batch(max_batch)
             e.set_lanes(lanes)

@@ -149,6 +149,10 @@ void acrmi_destroy(acrmi_ctx* ctx);
  * (BN folded, MFMA fragment order) copied once into HBM; static residency replaces
  * nn.DataParallel's per-call replicate (acr/main.py:61). */
 int acrmi_load_weights(acrmi_ctx* ctx, const float* blob_host, size_t n_floats);
+/* The same blob for several contexts of one device (a pool of contexts that take batches in turn): `ctx` uses
+ * the device copy `donor` holds instead of uploading its own - 330 MB per extra context at HRNet-W32 fp32.  The copy is freed
+ * when the last context holding it is destroyed or loads other weights.  Both contexts need the same program. */
+int acrmi_share_weights(acrmi_ctx* ctx, acrmi_ctx* donor);
 
 /* Lowered topology of acr/model.py:785-865 + :47-166; allocates activation buffers for
  * up to max_batch frames (aliasing non-overlapping lifetimes) and runs the init-time ops. */

@@ -520,6 +520,18 @@ def test_engine_pool_batches_equal_single_context(synth_sd, mano_tables):
     for w, g in zip(want, got):
         for k in ('slots', 'verts', 'joints'):
             assert torch.equal(w[k], g[k]), k
+    # the pool's contexts share ONE device copy of the weight blob (acrmi_share_weights): closing the context that
+    # uploaded it leaves the others working, and a sharing request across devices / without weights is refused
+    L = pkg('_lib')
+    assert L.lib().acrmi_share_weights(pool.engines[1].ctx, pool.engines[1].ctx) == -1      # ACRMI_EINVAL
+    fresh = pkg('engine').Engine(0)
+    assert L.lib().acrmi_share_weights(pool.engines[1].ctx, fresh.ctx) != 0      # the donor holds no weights
+    fresh.close()
+    pool.engines[0].close()
+    again = pool.engines[2].forward(batches[3])
+    torch.cuda.synchronize()
+    assert torch.equal(again['verts'], want[3]['verts'])
+    pool.engines = pool.engines[1:]
     pool.close()
     eng.close()
 
