@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from .packer import (DT_BF16, DT_F16, PRECISIONS, pack_conv, pack_conv_h16, pack_stem, pack_wino3, n_tiles_for,
-                     winograd_weights, winograd2d_weights, winograd24_weights)
+                     winograd_weights, winograd2d_weights, winograd24_weights, polyphase2_weights)
 
 
 def _p(t):
@@ -45,15 +45,19 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     cout = cout_t // groups
     b = np.zeros(cout_t, np.float32) if bias is None else (
         bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
-    if algo in ('winograd', 'winograd2d', 'winograd2d_lds', 'winograd24'):
+    if algo == 'polyphase2':
+        if k != 3 or stride != 2:
+            raise ValueError('the polyphase kernel is for 3x3 stride-2 convolutions')
+        tr = polyphase2_weights
+    elif algo in ('winograd', 'winograd2d', 'winograd2d_lds', 'winograd24'):
         if k != 3 or stride != 1:
             raise ValueError('winograd needs a 3x3 stride-1 convolution')
         tr = {'winograd': winograd_weights, 'winograd24': winograd24_weights}.get(algo, winograd2d_weights)
     elif algo == 'direct':
         tr = lambda t: t
     else:
-        raise ValueError('algo must be "direct", "winograd", "winograd2d", "winograd2d_lds" or "winograd24"')
-    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2, 'winograd2d_lds': 3, 'winograd24': 4}[algo]
+        raise ValueError('algo must be "direct", "winograd", "winograd2d", "winograd2d_lds", "winograd24" or "polyphase2"')
+    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2, 'winograd2d_lds': 3, 'winograd24': 4, 'polyphase2': 5}[algo]
     if algo_id == 3:
         if groups != 1 or cout != 32 or cin_g > 32:
             raise ValueError('winograd2d_lds needs groups = 1, Cout = 32, Cin <= 32')

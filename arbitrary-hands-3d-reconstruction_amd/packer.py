@@ -205,6 +205,39 @@ def winograd24_weights(w):
     return np.einsum('uy,vx,oiyx->oiuv', WINO_G, WINO_G4, np.asarray(w, np.float64))
 
 
+def polyphase2_weights(w):
+    """[Cout,Cin,3,3] -> [Cout,Cin,4,7]: the weights of conv_pp2_kernel (csrc/conv_pp2.inc), 3x3 stride 2 in polyphase form
+    with F(2,2) on the two-tap phases.  Per axis five 1-D terms: A0 = (d0 - d1) w0, A1 = d1 (w0 + w2), A2 = (d2 - d1) w2 on
+    the odd input rows, B0 / B1 = w1 on the even ones.  Wave (oy, ox) holds, in this order, its corner products
+    (Ya, Xa), (Ya, B), (B, Xa), (B, B) [Ya = A0 / A2 for oy = 0 / 1], two edge products (Ya, A1), (B, A1) - the waves with
+    oy != ox read the TRANSPOSED pixel set, which makes theirs (B, Xa) before (Ya, B) and (A1, Xa), (A1, B) - and the centre
+    (A1, A1) (every wave computes it, wave 0's copy is used).  fp64 in, rounded once by pack_conv."""
+    assert w.shape[2:] == (3, 3)
+    w = np.asarray(w, np.float64)
+    c = {'A0': (1.0, 0.0, 0.0), 'A1': (1.0, 0.0, 1.0), 'A2': (0.0, 0.0, 1.0), 'B': (0.0, 1.0, 0.0)}
+    out = np.zeros(w.shape[:2] + (4, 7))
+    for oy in range(2):
+        for ox in range(2):
+            ya, xa = ('A0', 'A2')[oy], ('A0', 'A2')[ox]
+            if oy == ox:
+                prods = [(ya, xa), (ya, 'B'), ('B', xa), ('B', 'B'), (ya, 'A1'), ('B', 'A1'), ('A1', 'A1')]
+            else:
+                prods = [(ya, xa), ('B', xa), (ya, 'B'), ('B', 'B'), ('A1', xa), ('A1', 'B'), ('A1', 'A1')]
+            for kk, (ty, tx) in enumerate(prods):
+                out[:, :, 2 * oy + ox, kk] = np.einsum('oiyx,y,x->oi', w, np.array(c[ty]), np.array(c[tx]))
+    return out
+
+
+# 3x3 stride-2 convs on the four-wave frame in polyphase form (algo 5, conv_pp2.inc: 25 products per 2x2 output block
+# instead of 36).  ACRMI_PP2=0 keeps the direct kernel (A/B runs).
+POLYPHASE2 = __import__('os').environ.get('ACRMI_PP2', '1') != '0'
+
+
+def polyphase2_ok(cin, cout, ho, wo):
+    """conv_pp2_kernel takes the layer (csrc/conv_pp2.inc pp2_ok; ho, wo = OUTPUT map, the input is twice that)."""
+    return cin % 16 == 0 and cout % 32 == 0 and ho % 8 == 0 and wo % 16 == 0
+
+
 def use_winograd(k, stride):
     return k == 3 and stride == 1
 
@@ -236,9 +269,13 @@ def wino24b_width(cin, cout, ho, wo):
 
 
 def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, wino24=None):
-    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3).
+    """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3),
+    5 polyphase F(2,2) (3x3 stride 2).
     wino24: None = WINOGRAD_24; False keeps the F(2x2,3x3) kernels for the layers F(2x4,3x3) would take (small batches:
     its 8x32-pixel, one-n-tile items are half as many as conv_wino2's small-batch items)."""
+    if k == 3 and stride == 2:
+        big = WINOGRAD_24 if wino24 is None else wino24       # (the large-batch lowering: items of 8x16 output pixels)
+        return 5 if (POLYPHASE2 and big and polyphase2_ok(cin, cout, ho, wo)) else 0
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
     if (WINOGRAD_2D and WINOGRAD_LDS and groups == 1 and cin <= 32 and cout == 32 and ho % 8 == 0 and wo % 16 == 0
@@ -466,7 +503,7 @@ class Program(object):
             if algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:
-                tr = (lambda t: t, winograd_weights, winograd2d_weights, None, winograd24_weights)[algo]
+                tr = (lambda t: t, winograd_weights, winograd2d_weights, None, winograd24_weights, polyphase2_weights)[algo]
                 packed = [pack_conv(tr(w), b) for (w, b) in wb_list]
             w_off = self.blob.add(np.concatenate([p[0] for p in packed]))
         b_off = self.blob.add(np.concatenate([p[1] for p in packed]))
@@ -483,13 +520,14 @@ class Program(object):
             self.ops[-1].flags = algo | _lib.CONV_BIAS_MAP
             self.ops[-1].w_off2 = self.blob.add(bias_map)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
-                                    'winograd_f2x4_3x3')[algo] + ('_splitk%d' % slices if slices > 1 else '')
+                                    'winograd_f2x4_3x3', 'polyphase_f2x2_s2')[algo] + ('_splitk%d' % slices if slices > 1 else '')
         # what bench.py prints next to the PMC traffic: the kernel family launch_conv picks for this op (conv_mfma.hip /
         # conv_wino24b.inc wino24b_ok) and the op's ALGORITHMIC HBM bytes per frame - input slice + output (+ residual)
         # once, in their storage types
         ng = len(wb_list)
         esz = lambda b: 4 if self.dtype_of(b) == DT_F32 else 2
-        fam = ('conv_ws2_kernel', 'conv_wino_kernel', 'conv_wino2_kernel', 'conv_wino3_kernel', 'conv_wino24_kernel')[algo]
+        fam = ('conv_ws2_kernel', 'conv_wino_kernel', 'conv_wino2_kernel', 'conv_wino3_kernel', 'conv_wino24_kernel',
+               'conv_pp2_kernel')[algo]
         if algo == 4 and wino24b_width(cin, cout, ho, wo):
             fam = 'conv_wino24b_kernel'
         if self.dt != DT_F32:

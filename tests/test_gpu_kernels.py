@@ -240,6 +240,55 @@ def test_conv2d_winograd24_four_wave_frame(ops, case):
         assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
 
 
+PP2_CASES = [
+    # (B, Cin, Cout, H, W (INPUT map), groups, relu, residual kind: 0 none / 1 per frame / 2 one map for every frame, frame_bias)
+    (2, 32, 64, 32, 64, 1, False, 0, False),       # HRNet fuse chain 32 -> 64: two chunks, 2x2 tiles (all border kinds of a stride-2 map)
+    (20, 64, 64, 64, 64, 1, True, 0, False),       # more items than workgroups can hold at once
+    (3, 32, 32, 48, 96, 1, True, 1, False),        # one n-tile per wave; interior tiles; residual per frame
+    (2, 16, 64, 16, 32, 1, True, 0, False),        # single-chunk items (Cin = 16), one tile per frame
+    (2, 48, 128, 16, 64, 1, False, 2, True),       # three chunks, two n-blocks, map residual + per-frame bias rows, no ReLU
+    (1, 256, 64, 32, 32, 1, True, 1, False),       # 16 chunks (layer1 -> transition1 branch 1)
+    (2, 64, 192, 32, 32, 2, True, 0, False),       # two groups of 32 -> 96 (one n-tile per wave, three n-blocks each)
+    (1, 128, 256, 32, 64, 1, False, 0, False),     # transition3: 128 -> 256
+]
+
+
+@pytest.mark.parametrize('case', PP2_CASES, ids=lambda c: 'pp2_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv2d_stride2_polyphase(ops, case):
+    """conv_pp2_kernel (3x3 stride 2 in polyphase form with F(2,2) on the two-tap phases, four-wave frame: 25 products per
+    2x2 output block instead of 36) vs an fp64 direct convolution and vs the direct stride-2 kernel.  Input, residual and
+    output live in channel slices of wider buffers; the neighbour channels must stay untouched."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 250)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 3, 3, generator=g) / np.sqrt(cin // groups * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 2, 1, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B if res_kind == 1 else 1, cout, H // 2, W // 2), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    errs = {}
+    for algo in ('polyphase2', 'direct'):
+        dst = torch.full((B, H // 2, W // 2, cout + 16), 7.0, device='cuda')     # output into channels 8..
+        ops.conv2d(xin, w, None if use_fb else b, stride=2, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo=algo,
+                   out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                   frame_bias=None if fb is None else fb.cuda())
+        torch.cuda.synchronize()
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        errs[algo] = (got.double() - ref).abs().max().item()
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), algo
+    assert errs['polyphase2'] < 1e-4, errs
+    assert errs['polyphase2'] < 4 * errs['direct'] + 1e-6, errs      # round-off of the same order as the direct kernel's
+
+
 WINO3_CASES = [
     # B, Cin, H, W, relu, residual
     (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)

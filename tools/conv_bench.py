@@ -39,6 +39,10 @@ SHAPES = [
     ('s2 256->64 3x3s2 @128', 256, 64, 128, 128, 3, 2, 1, False),
     ('entry 34->512 3x3s2 @128', 34, 512, 128, 128, 3, 2, 1, False),
     ('fuse 32->64 3x3s2 @128', 32, 64, 128, 128, 3, 2, 1, False),
+    ('fuse 32->32 3x3s2 @128', 32, 32, 128, 128, 3, 2, 1, False),
+    ('fuse 64->128 3x3s2 @64', 64, 128, 64, 64, 3, 2, 1, False),
+    ('fuse 128->256 3x3s2 @32', 128, 256, 32, 32, 3, 2, 1, False),
+    ('entry 32->512 3x3s2 @128 (+map)', 32, 512, 128, 128, 3, 2, 1, False),
 ]
 
 
@@ -52,6 +56,7 @@ def main():
     ap.add_argument('--wino2', action='store_true', help='... through the 2-D Winograd F(2x2,3x3) kernel')
     ap.add_argument('--wino24', action='store_true', help='... Cin > 16 shapes through the F(2x4,3x3) kernel (others as --wino2)')
     ap.add_argument('--wino3', action='store_true', help='... Cin<=32/Cout=32 shapes through the LDS-resident F(2x2,3x3) kernel')
+    ap.add_argument('--pp2', action='store_true', help='3x3 stride-2 shapes through the polyphase kernel (conv_pp2.inc)')
     ap.add_argument('--h16', default='', help="'fp16' | 'bf16': the 16-bit direct kernels (conv_h16.hip) on 16-bit tensors")
     ap.add_argument('--phase', type=int, default=0, help='loader-wave tuning switch: 8 = idle loader (timing ablation, wrong results), 9 = loader at priority 0')
     ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
@@ -114,11 +119,14 @@ def main():
             wino = 2 if (args.wino2 or args.wino3 or args.wino24) else (1 if args.wino else 0)
             if args.wino24 and coutg != 33 and ((cing > 32 and W % 32 == 0) or packer.wino24b_width(cing, coutg, H, W)):
                 wino = 4      # (incl. Cin = 32 shapes: the four-wave frame's single-chunk kernels, also where the program keeps conv_wino3)
+        if args.pp2 and k == 3 and stride == 2 and packer.polyphase2_ok(cing, coutg, H // 2, W // 2):
+            wino = 5
         if wino and args.wino3 and groups == 1 and cin <= 32 and cout == 32:
             wino = 3
             packed = [packer.pack_wino3(w.astype(np.float64), np.zeros(coutg, np.float32))]
         else:
-            tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights, None, packer.winograd24_weights)[wino]
+            tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights, None, packer.winograd24_weights,
+                  packer.polyphase2_weights)[wino]
             packed = [packer.pack_conv(tr(w), np.zeros(coutg, np.float32)) for _ in range(groups)]
         wp = torch.from_numpy(np.concatenate([q[0] for q in packed])).cuda()
         bp = torch.from_numpy(np.concatenate([q[1] for q in packed])).cuda()
