@@ -75,7 +75,8 @@ def pack_conv(w, b):
 
 
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
-PRECISIONS = {'fp32': DT_F32, 'fp16': DT_F16, 'bf16': DT_BF16}
+# 'fp16x3': fp32 storage, split-f16 operands on the 16-bit matrix pipe where conv_x3_kernel takes the layer (algo 6)
+PRECISIONS = {'fp32': DT_F32, 'fp16': DT_F16, 'bf16': DT_BF16, 'fp16x3': DT_F32}
 
 
 def round_to(x, dt):
@@ -111,6 +112,33 @@ def pack_conv_h16(w, b, dt):
     bp = np.zeros(nt * 32, np.float32)
     bp[:cout] = b
     return to_bits16(np.ascontiguousarray(wp).reshape(-1), dt), bp
+
+
+def split16(x, dt=DT_F16):
+    """float64/32 array -> (hi, lo) as float32 arrays holding 16-bit values: hi = round16(x), lo = round16(x - hi)."""
+    x = np.asarray(x, np.float64)
+    hi = round_to(x, dt).astype(np.float64)
+    lo = round_to(x - hi, dt)
+    return hi.astype(np.float32), lo
+
+
+def pack_conv_x3(w, b, dt=DT_F16):
+    """w [Cout,Cin,3,3] (Cin % 16 == 0), b [Cout] -> (split f16 weights as uint16 1-D, padded bias fp32 [n_tiles*32]) for
+    conv_x3_kernel (csrc/conv_x3.inc): the A fragments of v_mfma_f32_32x32x16_f16 of hi = f16(w) and lo = f16(w - hi),
+    1 KiB each, [tap][s = ci/16][ntile][hi | lo][lane 64][e 8], cout = ntile*32 + (lane & 31), ci = 16*s + 8*(lane >> 5) + e."""
+    cout, cin, kh, kw = w.shape
+    assert cin % 16 == 0
+    nt = n_tiles_for(cout)
+    c16 = cin // 16
+    wp = np.zeros((nt * 32, cin, kh, kw), np.float64)
+    wp[:cout] = w
+    hi, lo = split16(wp, dt)
+    both = np.stack([hi, lo])                              # [hl, cout, cin, ky, kx]
+    both = both.reshape(2, nt, 32, c16, 2, 8, kh, kw)       # [hl, nt, j, s, h, e, ky, kx]
+    both = both.transpose(6, 7, 3, 1, 0, 4, 2, 5)           # [ky, kx, s, nt, hl, h, j, e]
+    bp = np.zeros(nt * 32, np.float32)
+    bp[:cout] = b
+    return to_bits16(np.ascontiguousarray(both).reshape(-1), dt), bp
 
 
 def pack_wino3(w, b):
@@ -238,6 +266,13 @@ def polyphase2_ok(cin, cout, ho, wo):
     return cin % 16 == 0 and cout % 32 == 0 and ho % 8 == 0 and wo % 16 == 0
 
 
+# Split-operand 16-bit program ('fp16x3': fp32 storage, every operand of the eligible convolutions split into two f16
+# numbers, three products per MAC on the 16-bit matrix pipe with fp32 accumulation - csrc/conv_x3.inc, algo 6).
+def split16_ok(k, stride, cin, cout, ho, wo):
+    """conv_x3_kernel takes the layer (csrc/conv_x3.inc x3_ok)."""
+    return k == 3 and stride == 1 and cin % 32 == 0 and cin >= 32 and cout % 32 == 0 and ho % 8 == 0 and wo % 32 == 0
+
+
 def use_winograd(k, stride):
     return k == 3 and stride == 1
 
@@ -268,11 +303,13 @@ def wino24b_width(cin, cout, ho, wo):
     return 0
 
 
-def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, wino24=None):
+def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, wino24=None, split16=False):
     """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3),
-    5 polyphase F(2,2) (3x3 stride 2).
+    5 polyphase F(2,2) (3x3 stride 2), 6 split-f16 operands on the 16-bit matrix pipe (split16 programs only).
     wino24: None = WINOGRAD_24; False keeps the F(2x2,3x3) kernels for the layers F(2x4,3x3) would take (small batches:
     its 8x32-pixel, one-n-tile items are half as many as conv_wino2's small-batch items)."""
+    if split16 and split16_ok(k, stride, cin, cout, ho, wo):
+        return 6
     if k == 3 and stride == 2:
         big = WINOGRAD_24 if wino24 is None else wino24       # (the large-batch lowering: items of 8x16 output pixels)
         return 5 if (POLYPHASE2 and big and polyphase2_ok(cin, cout, ho, wo)) else 0
@@ -375,13 +412,14 @@ class Blob(object):
 class Program(object):
     """Op list + buffer table under construction."""
 
-    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None, splitk=False, pairs=False):
+    def __init__(self, sd, dt=DT_F32, keep_weights=False, keep_all=False, wino24=None, splitk=False, pairs=False, split16=False):
         self.sd = {k: _np(v) for k, v in sd.items()}
         self.dt = dt             # storage type of the activations between layers (DT_*); head outputs stay fp32
         self.keep_weights = keep_weights
         self.splitk = splitk      # small-batch program: split-K lowering of the low-resolution 3x3 layers
         self.pairs = pairs and dt == DT_F32      # large-batch fp32 program: layer1's conv3 / next conv1 pairs as one op
         self.wino24 = wino24      # None = packer.WINOGRAD_24
+        self.split16 = split16 and dt == DT_F32      # 'fp16x3' program
         self.keep_all = keep_all  # no lifetime-based buffer reuse: every intermediate map survives the run (tests)
         self.blob = Blob()
         self.bufs = []           # (h, w, cs, persistent, dtype)
@@ -499,8 +537,12 @@ class Program(object):
             packed = [pack_conv_h16(w, b, self.dt) for (w, b) in wb_list]
             w_off = self.blob.add16(np.concatenate([p[0] for p in packed]))
         else:
-            algo = 2 if slices > 1 else conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24)
-            if algo == 3:
+            algo = 2 if slices > 1 else conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24,
+                                                    self.split16)
+            if algo == 6:
+                packed = [pack_conv_x3(w, b) for (w, b) in wb_list]
+                packed = [(p[0].view(np.float32), p[1]) for p in packed]      # (1 KiB fragments: whole floats)
+            elif algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:
                 tr = (lambda t: t, winograd_weights, winograd2d_weights, None, winograd24_weights, polyphase2_weights)[algo]
@@ -520,14 +562,14 @@ class Program(object):
             self.ops[-1].flags = algo | _lib.CONV_BIAS_MAP
             self.ops[-1].w_off2 = self.blob.add(bias_map)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
-                                    'winograd_f2x4_3x3', 'polyphase_f2x2_s2')[algo] + ('_splitk%d' % slices if slices > 1 else '')
+                                    'winograd_f2x4_3x3', 'polyphase_f2x2_s2', 'split_f16x3')[algo] + ('_splitk%d' % slices if slices > 1 else '')
         # what bench.py prints next to the PMC traffic: the kernel family launch_conv picks for this op (conv_mfma.hip /
         # conv_wino24b.inc wino24b_ok) and the op's ALGORITHMIC HBM bytes per frame - input slice + output (+ residual)
         # once, in their storage types
         ng = len(wb_list)
         esz = lambda b: 4 if self.dtype_of(b) == DT_F32 else 2
         fam = ('conv_ws2_kernel', 'conv_wino_kernel', 'conv_wino2_kernel', 'conv_wino3_kernel', 'conv_wino24_kernel',
-               'conv_pp2_kernel')[algo]
+               'conv_pp2_kernel', 'conv_x3_kernel')[algo]
         if algo == 4 and wino24b_width(cin, cout, ho, wo):
             fam = 'conv_wino24b_kernel'
         if self.dt != DT_F32:
@@ -730,7 +772,8 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     c0 = backbone_channels(width)
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
-    P = Program(sd, dt, keep_weights, keep_all, wino24, splitk, FUSE_PAIRS and not splitk if pairs is None else pairs)
+    P = Program(sd, dt, keep_weights, keep_all, wino24, splitk, FUSE_PAIRS and not splitk if pairs is None else pairs,
+                split16=precision == 'fp16x3')
     b = 'backbone.'
     taps = {}
     x34 = None

@@ -289,6 +289,56 @@ def test_conv2d_stride2_polyphase(ops, case):
     assert errs['polyphase2'] < 4 * errs['direct'] + 1e-6, errs      # round-off of the same order as the direct kernel's
 
 
+X3_CASES = [
+    # (B, Cin, Cout, H, W, groups, relu, residual kind: 0 none / 1 per frame / 2 one map for every frame, frame_bias)
+    (2, 64, 64, 64, 64, 1, True, 1, False),        # HRNet branch 1: two chunks, all four border kinds
+    (20, 64, 64, 64, 64, 1, True, 1, False),       # 320 items: more than one item per workgroup
+    (3, 128, 128, 32, 32, 1, True, 0, False),      # branch 2: four chunks, two n-blocks, every tile touches left AND right
+    (1, 512, 512, 64, 64, 8, True, 1, False),      # the eight head towers as groups
+    (2, 96, 128, 8, 32, 1, False, 2, False),       # three chunks, one tile per frame (all four borders), no ReLU, map residual
+    (2, 64, 64, 16, 96, 1, False, 0, True),        # interior tile columns, per-frame bias rows
+    (3, 32, 256, 32, 64, 1, True, 2, False),       # single-chunk items (Cin = 32): the contact conv + its bias map
+    (2, 256, 32, 32, 64, 1, True, 1, False),       # one n-tile per wave (Cout = 32), 8 chunks
+    (3, 32, 32, 24, 64, 1, True, 1, False),        # single chunk AND one n-tile (HRNet branch 0)
+]
+
+
+@pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'x3_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv2d_split_f16_operands(ops, case):
+    """conv_x3_kernel (fp32 storage; every operand split into hi + lo f16, three products per MAC on
+    v_mfma_f32_32x32x16_f16, fp32 accumulation) vs an fp64 direct convolution and vs the fp32 Winograd kernel on the same
+    data: the round-off must be of the fp32 kernels' order.  Channel slices of wider buffers; neighbours untouched."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 260)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 3, 3, generator=g) / np.sqrt(cin // groups * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 1, 1, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B if res_kind == 1 else 1, cout, H, W), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    errs = {}
+    for algo in ('split16', 'winograd2d'):
+        dst = torch.full((B, H, W, cout + 16), 7.0, device='cuda')     # output into channels 8..
+        ops.conv2d(xin, w, None if use_fb else b, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo=algo,
+                   out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                   frame_bias=None if fb is None else fb.cuda())
+        torch.cuda.synchronize()
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        errs[algo] = (got.double() - ref).abs().max().item()
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), algo
+    assert errs['split16'] < 2e-5, errs
+    assert errs['split16'] < 4 * errs['winograd2d'] + 1e-6, errs
+
+
 WINO3_CASES = [
     # B, Cin, H, W, relu, residual
     (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)

@@ -57,6 +57,7 @@ def main():
     ap.add_argument('--wino24', action='store_true', help='... Cin > 16 shapes through the F(2x4,3x3) kernel (others as --wino2)')
     ap.add_argument('--wino3', action='store_true', help='... Cin<=32/Cout=32 shapes through the LDS-resident F(2x2,3x3) kernel')
     ap.add_argument('--pp2', action='store_true', help='3x3 stride-2 shapes through the polyphase kernel (conv_pp2.inc)')
+    ap.add_argument('--x3', action='store_true', help='3x3 stride-1 shapes through the split-f16 kernel (conv_x3.inc)')
     ap.add_argument('--h16', default='', help="'fp16' | 'bf16': the 16-bit direct kernels (conv_h16.hip) on 16-bit tensors")
     ap.add_argument('--phase', type=int, default=0, help='loader-wave tuning switch: 8 = idle loader (timing ablation, wrong results), 9 = loader at priority 0')
     ap.add_argument('--stamps', action='store_true', help='print clock64 deltas of workgroup 0 (ws kernel)')
@@ -121,9 +122,14 @@ def main():
                 wino = 4      # (incl. Cin = 32 shapes: the four-wave frame's single-chunk kernels, also where the program keeps conv_wino3)
         if args.pp2 and k == 3 and stride == 2 and packer.polyphase2_ok(cing, coutg, H // 2, W // 2):
             wino = 5
+        x3 = args.x3 and packer.split16_ok(k, stride, cing, coutg, H, W)
         if wino and args.wino3 and groups == 1 and cin <= 32 and cout == 32:
             wino = 3
             packed = [packer.pack_wino3(w.astype(np.float64), np.zeros(coutg, np.float32))]
+        elif x3:
+            wino = 6
+            packed = [packer.pack_conv_x3(w.astype(np.float64), np.zeros(coutg, np.float32)) for _ in range(groups)]
+            packed = [(q[0].view(np.float32), q[1]) for q in packed]
         else:
             tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights, None, packer.winograd24_weights,
                   packer.polyphase2_weights)[wino]
