@@ -128,11 +128,13 @@ def parity(eng, oracle):
             'against': 'oracle/ (CPU fp32 restatement pinned to the reference) on the cpu_baseline sample frames'}
 
 
-def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16', 'bf16')):
+def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16', 'bf16', 'fp16x3')):
     """Reported NEXT TO the headline, never as it: the reference's --model_precision fp16 branch (acr/model.py:33-37) and
     its bf16 twin as 16-bit programs (packer.lower) on the same frames, same K steps, two contexts in turn like the
     headline; `parity` = against the fp32 oracle (what 16-bit storage costs), not against a 16-bit reference (none
-    exists: autocast is CUDA-only)."""
+    exists: autocast is CUDA-only).  'fp16x3' = fp32 STORAGE with split operands on the 16-bit matrix pipe (csrc/conv_x3.inc:
+    x = hi + lo in f16, three products per MAC, fp32 accumulation) for the 3x3 stride-1 layers it takes; every other op is
+    the fp32 program's."""
     res = {}
     for prec in precisions:
         pool = pkg('engine').EnginePool(local_rank, n=2)
@@ -170,7 +172,9 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
                                    bufs_[o.out_buf][0] * bufs_[o.out_buf][1] * o.cout * o.groups * esz(o.out_buf) *
                                    (2 if o.res_buf >= 0 else 1))
         r = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
-             'dtype': {'fp16': 'f16', 'bf16': 'bf16'}[prec] + ' storage, f32 accumulate (v_mfma_f32_32x32x16)',
+             'dtype': ('f32 storage; 3x3 stride-1 layers: operands split into f16 hi + lo, 3 products per MAC on '
+                       'v_mfma_f32_32x32x16_f16, f32 accumulate; other ops as the fp32 program' if prec == 'fp16x3' else
+                       {'fp16': 'f16', 'bf16': 'bf16'}[prec] + ' storage, f32 accumulate (v_mfma_f32_32x32x16)'),
              'all_conv_ms_single_stream': round(conv_ms, 3), 'all_ops_ms_single_stream': round(total_ms, 3),
              'mfma_tflops_single_stream': round(flops / (total_ms * 1e-3) / 1e12, 1), 'mfma_peak_tflops': 2500.0,
              'roofline': {'bound': 'hbm', 'achieved': round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
@@ -181,9 +185,11 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
             r['parity'] = parity(eng, oracle)
         res[prec] = r
         pool.close()
-    res['note'] = ('16-bit programs: activations between layers f16 / bf16 NHWC, BN-folded weights rounded once, fp32 '
+    res['note'] = ('fp16 / bf16: activations between layers f16 / bf16 NHWC, BN-folded weights rounded once, fp32 '
                    'accumulate / bias / residual / ReLU, one rounding per layer; stem, head exits, attention pooling, '
-                   'decode, MANO fp32.  parity is against the FP32 oracle.')
+                   'decode, MANO fp32.  fp16x3: activations and weights stay fp32 in memory; conv_x3_kernel splits every '
+                   'operand into two f16 numbers (22 bits) and multiplies on the 16-bit matrix pipe - the accuracy of the '
+                   'fp32 program at a higher rate.  parity is against the FP32 oracle.')
     return res
 
 

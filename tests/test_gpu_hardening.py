@@ -137,6 +137,65 @@ def test_hostile_checkpoint_against_the_reference_and_per_layer_winograd_error(m
     eng.close()
 
 
+def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
+    """The 'fp16x3' program (fp32 storage; the 3x3 stride-1 layers on conv_x3_kernel: operands split into f16 hi + lo, three
+    products per MAC on the 16-bit matrix pipe, fp32 accumulation) on the hostile checkpoint: (1) end to end against the
+    real reference (e2e_batch1.npz) - decisions identical, vertices / joints inside the 1e-4 m budget of the fp32 program;
+    (2) per layer: every split-operand launch against an exact fp64 convolution of the GPU's own input buffer - the same
+    2e-5 bound (relative to the layer's largest output) the fp32 Winograd kernels are held to."""
+    synth = pkg('synth')
+    L = pkg('_lib')
+    hs = synth.make_state_dict(seed=0, law='hostile')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(hs, max_batch=2, keep_weights=True, keep_all=True, wino24=True, splitk=False, precision='fp16x3')
+    eng.load_mano(_flip_left(mano_tables))
+    g = golden('e2e_batch1.npz')
+    x = torch.from_numpy(frames2)
+    out = eng.forward(x.cuda())
+    torch.cuda.synchronize()
+    slots = out['slots'].cpu().numpy()
+    worst_v = 0.0
+    for b in range(2):
+        np.testing.assert_array_equal(slots[b, :, L.SLOT_FLAG] > 0.5, g['f%d_detection_flag' % b].astype(bool))
+        lc, rc = g['f%d_l_centers_pred' % b][0], g['f%d_r_centers_pred' % b][0]
+        assert slots[b, 0, L.SLOT_FLATIND] == lc[1] * 64 + lc[0] and slots[b, 1, L.SLOT_FLATIND] == rc[1] * 64 + rc[0]
+        worst_v = max(worst_v, float(np.abs(out['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max()),
+                      float(np.abs(out['joints'][b].cpu().numpy() - g['f%d_j3d' % b]).max()))
+    assert worst_v < 1e-4, worst_v
+    prog = eng.program
+    B = 1
+    eng.backbone_heads(x[:1].cuda())
+    torch.cuda.synchronize()
+    hip = [eng.buffer(i, B).float().cpu() for i in range(len(prog['bufs']))]
+    it = oprog.Interp(prog, B)
+    it.bufs = [b.clone() for b in hip]
+    rows = []
+    for i, (op, info) in enumerate(zip(prog['ops'], prog['op_info'])):
+        if op.mode == oprog.MODE_POINT or op.kind != oprog.OP_CONV or op.res_buf == op.out_buf or info.get('algo') != 'split_f16x3':
+            continue
+        later_in_place = any(o.kind == oprog.OP_CONV and o.res_buf == o.out_buf and o.out_buf == op.out_buf
+                             for o in prog['ops'][i + 1:]) or any(o.kind == oprog.OP_POW11 and o.out_buf == op.out_buf
+                                                                   for o in prog['ops'][i + 1:])
+        if later_in_place:
+            continue
+        it.conv(op, info)
+        n = op.groups * op.cout
+        want = it.bufs[op.out_buf][..., op.out_coff:op.out_coff + n]
+        got = hip[op.out_buf][..., op.out_coff:op.out_coff + n]
+        scale = float(want.abs().max())
+        rows.append({'op': info['name'], 'rel_err': float((want - got).abs().max()) / max(scale, 1e-20), 'out_absmax': scale,
+                     'in_absmax': float(hip[op.in_buf][..., op.in_coff:op.in_coff + op.groups * op.cin].abs().max())})
+        it.bufs[op.out_buf] = hip[op.out_buf].clone()
+    rows.sort(key=lambda r: -r['rel_err'])
+    rep = {'end_to_end_max_vertex_joint_abs_err_m': worst_v, 'split_operand_layers': len(rows),
+           'worst_rel_err': rows[0]['rel_err'], 'max_activation': max(r['in_absmax'] for r in rows), 'worst_layers': rows[:5]}
+    _report('hostile_checkpoint_fp16x3', rep)
+    assert len(rows) >= 150
+    assert rep['max_activation'] < 65504.0          # the f16 range the split needs
+    assert rep['worst_rel_err'] < 2e-5, rep
+    eng.close()
+
+
 def test_hostile_checkpoint_on_the_small_batch_lowering(mano_tables, frames2):
     """The same hostile checkpoint on a small-batch context (F(2x2,3x3) everywhere, the low-resolution branches as
     split-K launches whose partial tiles are summed by the last arriver): decisions identical to the real reference's,

@@ -240,3 +240,88 @@ def test_reference_batch_semantics_host_logic(name):
     assert list(meta['imgpath']) == ['f%d' % b for b in g[name + '_reorganize_idx']]
     with pytest.raises(ValueError):
         rp.ResultParser(batch_semantics='whole-batch')
+
+
+def test_polyphase2_weights_reproduce_the_stride2_convolution():
+    """packer.polyphase2_weights + the accumulation scheme of csrc/conv_pp2.inc, emulated in numpy: per 2x2 output block
+    every wave (oy, ox) forms its seven input combinations from a 3x3 subset of the block's 5x5 window (transposed for the
+    waves with oy != ox), accumulates corner / edge / centre products, and output (oy, ox) is its own corner + the two edge
+    tiles that carry its row / column + wave 0's centre - 25 products instead of 36.  Must equal a stride-2 convolution."""
+    packer = pkg('packer')
+    rng = np.random.default_rng(5)
+    cin, cout, H, W = 5, 4, 8, 12
+    x = rng.standard_normal((cin, H, W))
+    w = rng.standard_normal((cout, cin, 3, 3))
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), None, 2, 1)[0].numpy()
+    U = packer.polyphase2_weights(w)                       # [cout, cin, 4 waves, 7]
+    assert U.shape == (cout, cin, 4, 7)
+    xp = np.zeros((cin, H + 1, W + 1))
+    xp[:, 1:, 1:] = x                                     # the patch origin is (-1, -1); even H, W: no bottom / right ring
+    out = np.zeros_like(ref)
+    for R in range(H // 4):
+        for C in range(W // 4):
+            win = xp[:, 4 * R:4 * R + 5, 4 * C:4 * C + 5]   # the block's 5x5 window
+            acc = {}
+            for oy in range(2):
+                for ox in range(2):
+                    yi, xj = [4 * oy, 2, 1 + 2 * oy], [4 * ox, 2, 1 + 2 * ox]
+                    tr = oy != ox
+                    P = [[win[:, yi[v], xj[u]] if tr else win[:, yi[u], xj[v]] for v in range(3)] for u in range(3)]
+                    D = [P[0][v] - P[1][v] for v in range(3)]
+                    k = [D[0] - D[1], D[2], P[2][0] - P[2][1], P[2][2], D[1], P[2][1], P[1][1]]
+                    wv = 2 * oy + ox
+                    prod = [U[:, :, wv, i] @ k[i] for i in range(7)]
+                    acc[wv] = (prod[0] + prod[1] + prod[2] + prod[3], prod[4] + prod[5], prod[6])
+            for oy in range(2):
+                for ox in range(2):
+                    wv = 2 * oy + ox
+                    out[:, 2 * R + oy, 2 * C + ox] = acc[wv][0] + acc[3 * oy][1] + acc[2 - ox][1] + acc[0][2]
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+    assert packer.conv_algo(3, 2, 32, 64, 1, 64, 64) == 5 and packer.conv_algo(3, 2, 32, 64, 1, 64, 64, wino24=False) == 0
+    assert packer.conv_algo(3, 2, 24, 64, 1, 64, 64) == 0 and packer.conv_algo(3, 2, 32, 64, 1, 12, 64) == 0
+
+
+def test_split16_and_pack_conv_x3_layout():
+    """packer.split16: hi + lo reproduces the value to 2^-22 |x| + 2^-25 (the second term: lo falls into the f16 subnormals
+    for |x| < 2^-3 - an ABSOLUTE error of at most half their spacing, 3e-8); pack_conv_x3 puts the two halves where
+    conv_x3_kernel reads them ([tap][cin / 16][n-tile][hi | lo][lane][8]); conv_algo routes only split16 programs to algo 6."""
+    packer = pkg('packer')
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(4096) * np.exp(rng.uniform(-6, 6, 4096))
+    hi, lo = packer.split16(x)
+    assert np.all(hi == hi.astype(np.float16)) and np.all(lo == lo.astype(np.float16))
+    assert np.all(np.abs(hi.astype(np.float64) + lo - x) <= 2.0 ** -22 * np.abs(x) + 2.0 ** -25)
+    w = rng.standard_normal((40, 32, 3, 3))
+    b = rng.standard_normal(40)
+    bits, bp = packer.pack_conv_x3(w, b)
+    nt = packer.n_tiles_for(40)
+    arr = bits.view(np.float16).astype(np.float64).reshape(3, 3, 2, nt, 2, 2, 32, 8)     # [ky, kx, s, nt, hl, kg, j, e]
+    assert bits.size * 2 == 9 * 2 * nt * 2 * 1024 and bits.view(np.float32).size == 9 * (32 // 8) * nt * 256
+    for (ky, kx, s, n, kgp, j, e) in [(0, 0, 0, 0, 0, 0, 0), (2, 1, 1, 1, 1, 7, 5), (1, 2, 0, 0, 1, 31, 7)]:
+        co, ci = 32 * n + j, 16 * s + 8 * kgp + e
+        want = w[co, ci, ky, kx] if co < 40 else 0.0
+        assert abs(arr[ky, kx, s, n, 0, kgp, j, e] + arr[ky, kx, s, n, 1, kgp, j, e] - want) <= 2.0 ** -22 * abs(want) + 2.0 ** -25
+    np.testing.assert_array_equal(bp[:40], b.astype(np.float32))
+    assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16=True) == 6 and packer.conv_algo(3, 1, 64, 64, 1, 64, 64) == 4
+    assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 4 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2
+
+
+def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
+    """'fp16x3' lowers to the SAME op list, buffers and biases as 'fp32' - only the eligible 3x3 stride-1 convolutions
+    change their kernel (algo 6) and weight packing."""
+    packer, L = pkg('packer'), pkg('_lib')
+    p32 = packer.lower(synth_sd, precision='fp32', point_heads=False)
+    px3 = packer.lower(synth_sd, precision='fp16x3', point_heads=False)
+    assert px3['bufs'] == p32['bufs'] and len(px3['ops']) == len(p32['ops'])
+    n6 = 0
+    for a, b in zip(p32['ops'], px3['ops']):
+        assert (a.kind, a.in_buf, a.out_buf, a.res_buf, a.cin, a.cout, a.ksize, a.stride, a.groups) == (
+            b.kind, b.in_buf, b.out_buf, b.res_buf, b.cin, b.cout, b.ksize, b.stride, b.groups)
+        if b.kind == L.OP_CONV and (b.flags & 7) == 6:
+            n6 += 1
+            assert (a.flags & 7) in (3, 4) and b.ksize == 3 and b.stride == 1
+        else:
+            assert a.flags == b.flags
+    assert n6 >= 190
+    with pytest.raises(ValueError):
+        packer.lower(synth_sd, precision='fp8')

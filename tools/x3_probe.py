@@ -38,6 +38,16 @@ for prec in ('fp32', 'fp16x3'):
     for i in eng.program['op_info']:
         algos[i.get('algo')] = algos.get(i.get('algo'), 0) + 1
     print('%s: %.3f ms per batch of %d = %.1f frames/s (one context); ops by algo: %s' % (prec, dt * 1e3, B, B / dt, algos), flush=True)
+    fam = {}
+    for pr in eng.profile_ops(frames):
+        if pr.get('mode', 0) == L.MODE_POINT:
+            continue
+        info = eng.program['op_info'][pr['idx']]
+        key = info.get('kernel') or info.get('algo') or str(pr['kind'])
+        f = fam.setdefault(key, [0, 0.0])
+        f[0] += 1
+        f[1] += pr['ms']
+    print('   ' + ', '.join('%s x%d %.2f ms' % (k_, v_[0], v_[1]) for k_, v_ in sorted(fam.items(), key=lambda kv: -kv[1][1])), flush=True)
     res[prec] = {k: v.cpu().numpy().copy() for k, v in views.items()}
     eng.close() if hasattr(eng, 'close') else None
 a, b = res['fp32'], res['fp16x3']
