@@ -408,7 +408,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         return fail(c, ACRMI_EINVAL, "op %d: algo 5 needs fp32, Cin %% 16 = 0, Cout %% 32 = 0, an output map of 8x16-pixel tiles", i);
       const long long taps = algo == 6 ? 9 : algo == 5 ? 28 : algo == 4 ? 24 : (algo >= 2 ? 16 : (algo == 1 ? 12 : op.ksize * op.ksize));
       const long long ksteps = idt ? (op.cin + 15) / 16 : (op.cin + 7) / 8;      // 1 KiB weight fragments per tap and n-tile
-      const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ksteps * n_tiles * 256;
+      const long long wn = algo == 3 ? 16384 : (long long)op.groups * taps * ksteps * n_tiles * 256 + (algo == 6 ? 1 : 0);      // (algo 6: + the weight scale)
       if (!w_ok(op.w_off, wn)) return fail(c, ACRMI_EINVAL, "op %d: packed weights outside the blob", i);
       if (op.bias_per_frame) {
         if (!buf_ok(op.aux_buf) || bufs[op.aux_buf].cs < op.groups * op.cout)

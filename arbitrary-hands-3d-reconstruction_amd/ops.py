@@ -67,8 +67,7 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
             raise ValueError('winograd2d_lds needs groups = 1, Cout = 32, Cin <= 32')
         packed = [pack_wino3(w.astype(np.float64), b)]
     elif algo_id == 6:
-        packed = [pack_conv_x3(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout]) for g in range(groups)]
-        packed = [(p[0].view(np.float32), p[1]) for p in packed]
+        packed = [pack_conv_x3([(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout]) for g in range(groups)])]
     else:
         packed = [pack_conv(tr(w[g * cout:(g + 1) * cout].astype(np.float64)), b[g * cout:(g + 1) * cout])
                   for g in range(groups)]

@@ -122,23 +122,41 @@ def split16(x, dt=DT_F16):
     return hi.astype(np.float32), lo
 
 
-def pack_conv_x3(w, b, dt=DT_F16):
-    """w [Cout,Cin,3,3] (Cin % 16 == 0), b [Cout] -> (split f16 weights as uint16 1-D, padded bias fp32 [n_tiles*32]) for
-    conv_x3_kernel (csrc/conv_x3.inc): the A fragments of v_mfma_f32_32x32x16_f16 of hi = f16(w) and lo = f16(w - hi),
-    1 KiB each, [tap][s = ci/16][ntile][hi | lo][lane 64][e 8], cout = ntile*32 + (lane & 31), ci = 16*s + 8*(lane >> 5) + e."""
-    cout, cin, kh, kw = w.shape
-    assert cin % 16 == 0
-    nt = n_tiles_for(cout)
-    c16 = cin // 16
-    wp = np.zeros((nt * 32, cin, kh, kw), np.float64)
-    wp[:cout] = w
-    hi, lo = split16(wp, dt)
-    both = np.stack([hi, lo])                              # [hl, cout, cin, ky, kx]
-    both = both.reshape(2, nt, 32, c16, 2, 8, kh, kw)       # [hl, nt, j, s, h, e, ky, kx]
-    both = both.transpose(6, 7, 3, 1, 0, 4, 2, 5)           # [ky, kx, s, nt, hl, h, j, e]
-    bp = np.zeros(nt * 32, np.float32)
-    bp[:cout] = b
-    return to_bits16(np.ascontiguousarray(both).reshape(-1), dt), bp
+def x3_weight_shift(ws):
+    """Power-of-two pre-scaling of an op's filters for conv_x3_kernel: S with max |w| 2^S in [2^12, 2^13) (0 <= S <= 30), so
+    that lo = f16(w 2^S - hi) stays a NORMAL f16 number for every |w| >= 2^-16 max |w| (unscaled, a weight below 2^-3 has
+    its lo in the f16 subnormals: an absolute error of up to 3e-8 instead of 2^-22 |w|)."""
+    m = max(float(np.max(np.abs(w))) for w in ws)
+    if not np.isfinite(m) or m <= 0.0:
+        return 0
+    return int(min(30, max(0, 12 - int(np.floor(np.log2(m))))))
+
+
+def pack_conv_x3(wb_list, dt=DT_F16):
+    """[(w [Cout,Cin,3,3], b [Cout])] per group (Cin % 16 == 0) -> (float32 1-D holding the split f16 weights + one trailing
+    float, padded biases fp32 [groups][n_tiles*32]) for conv_x3_kernel (csrc/conv_x3.inc): the A fragments of
+    v_mfma_f32_32x32x16_f16 of hi = f16(w 2^S) and lo = f16(w 2^S - hi), 1 KiB each,
+    [group][tap][s = ci/16][ntile][hi | lo][lane 64][e 8], cout = ntile*32 + (lane & 31), ci = 16*s + 8*(lane >> 5) + e; the
+    trailing float is 2^-S (x3_weight_shift), which the kernel applies to the accumulators (exact)."""
+    shift = x3_weight_shift([w for (w, _) in wb_list])
+    out, biases = [], []
+    for (w, b) in wb_list:
+        cout, cin, kh, kw = w.shape
+        assert cin % 16 == 0
+        nt = n_tiles_for(cout)
+        c16 = cin // 16
+        wp = np.zeros((nt * 32, cin, kh, kw), np.float64)
+        wp[:cout] = np.asarray(w, np.float64) * 2.0 ** shift
+        hi, lo = split16(wp, dt)
+        both = np.stack([hi, lo])                              # [hl, cout, cin, ky, kx]
+        both = both.reshape(2, nt, 32, c16, 2, 8, kh, kw)       # [hl, nt, j, s, h, e, ky, kx]
+        both = both.transpose(6, 7, 3, 1, 0, 4, 2, 5)           # [ky, kx, s, nt, hl, h, j, e]
+        out.append(to_bits16(np.ascontiguousarray(both).reshape(-1), dt).view(np.float32))
+        bp = np.zeros(nt * 32, np.float32)
+        bp[:cout] = b
+        biases.append(bp)
+    out.append(np.array([2.0 ** -shift], np.float32))
+    return np.concatenate(out), np.concatenate(biases)
 
 
 def pack_wino3(w, b):
@@ -540,8 +558,7 @@ class Program(object):
             algo = 2 if slices > 1 else conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24,
                                                     self.split16)
             if algo == 6:
-                packed = [pack_conv_x3(w, b) for (w, b) in wb_list]
-                packed = [(p[0].view(np.float32), p[1]) for p in packed]      # (1 KiB fragments: whole floats)
+                packed = [pack_conv_x3(wb_list)]                 # (one power-of-two weight scale for the op: trailing float)
             elif algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:

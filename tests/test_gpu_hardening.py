@@ -142,7 +142,7 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
     products per MAC on the 16-bit matrix pipe, fp32 accumulation) on the hostile checkpoint: (1) end to end against the
     real reference (e2e_batch1.npz) - decisions identical, vertices / joints inside the 1e-4 m budget of the fp32 program;
     (2) per layer: every split-operand launch against an exact fp64 convolution of the GPU's own input buffer - the same
-    2e-5 bound (relative to the layer's largest output) the fp32 Winograd kernels are held to."""
+    bound relative to the layer's largest output is 5e-6 (the fp32 Winograd kernels are held to 2e-5)."""
     synth = pkg('synth')
     L = pkg('_lib')
     hs = synth.make_state_dict(seed=0, law='hostile')
@@ -161,7 +161,7 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
         assert slots[b, 0, L.SLOT_FLATIND] == lc[1] * 64 + lc[0] and slots[b, 1, L.SLOT_FLATIND] == rc[1] * 64 + rc[0]
         worst_v = max(worst_v, float(np.abs(out['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max()),
                       float(np.abs(out['joints'][b].cpu().numpy() - g['f%d_j3d' % b]).max()))
-    assert worst_v < 1e-4, worst_v
+    assert worst_v < 1e-5, worst_v      # (measured 3.7e-7 m; the fp32 program: 2.9e-7 m)
     prog = eng.program
     B = 1
     eng.backbone_heads(x[:1].cuda())
@@ -192,7 +192,7 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
     _report('hostile_checkpoint_fp16x3', rep)
     assert len(rows) >= 150
     assert rep['max_activation'] < 65504.0          # the f16 range the split needs
-    assert rep['worst_rel_err'] < 2e-5, rep
+    assert rep['worst_rel_err'] < 5e-6, rep      # (measured 1.5e-6; F(2x4,3x3) on the fp32 pipe: 1.2e-6)
     eng.close()
 
 

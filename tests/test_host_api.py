@@ -293,14 +293,17 @@ def test_split16_and_pack_conv_x3_layout():
     assert np.all(np.abs(hi.astype(np.float64) + lo - x) <= 2.0 ** -22 * np.abs(x) + 2.0 ** -25)
     w = rng.standard_normal((40, 32, 3, 3))
     b = rng.standard_normal(40)
-    bits, bp = packer.pack_conv_x3(w, b)
+    w[3] *= 2.0 ** -9                                       # a small filter row
+    packed, bp = packer.pack_conv_x3([(w, b)])
     nt = packer.n_tiles_for(40)
-    arr = bits.view(np.float16).astype(np.float64).reshape(3, 3, 2, nt, 2, 2, 32, 8)     # [ky, kx, s, nt, hl, kg, j, e]
-    assert bits.size * 2 == 9 * 2 * nt * 2 * 1024 and bits.view(np.float32).size == 9 * (32 // 8) * nt * 256
-    for (ky, kx, s, n, kgp, j, e) in [(0, 0, 0, 0, 0, 0, 0), (2, 1, 1, 1, 1, 7, 5), (1, 2, 0, 0, 1, 31, 7)]:
+    shift = packer.x3_weight_shift([w])
+    assert 2.0 ** 12 <= np.abs(w).max() * 2.0 ** shift < 2.0 ** 13 and packed[-1] == np.float32(2.0 ** -shift)
+    assert packed.size == 9 * (32 // 8) * nt * 256 + 1      # the fp32 packing's size + the scale
+    arr = packed[:-1].view(np.float16).astype(np.float64).reshape(3, 3, 2, nt, 2, 2, 32, 8) * 2.0 ** -shift     # [ky, kx, s, nt, hl, kg, j, e]
+    for (ky, kx, s, n, kgp, j, e) in [(0, 0, 0, 0, 0, 0, 0), (2, 1, 1, 1, 1, 7, 5), (1, 2, 0, 0, 1, 31, 7), (1, 1, 1, 0, 0, 3, 2)]:
         co, ci = 32 * n + j, 16 * s + 8 * kgp + e
         want = w[co, ci, ky, kx] if co < 40 else 0.0
-        assert abs(arr[ky, kx, s, n, 0, kgp, j, e] + arr[ky, kx, s, n, 1, kgp, j, e] - want) <= 2.0 ** -22 * abs(want) + 2.0 ** -25
+        assert abs(arr[ky, kx, s, n, 0, kgp, j, e] + arr[ky, kx, s, n, 1, kgp, j, e] - want) <= 2.0 ** -22 * abs(want)    # (scaled: no subnormal lo)
     np.testing.assert_array_equal(bp[:40], b.astype(np.float32))
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16=True) == 6 and packer.conv_algo(3, 1, 64, 64, 1, 64, 64) == 4
     assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 4 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2

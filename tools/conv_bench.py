@@ -128,8 +128,7 @@ def main():
             packed = [packer.pack_wino3(w.astype(np.float64), np.zeros(coutg, np.float32))]
         elif x3:
             wino = 6
-            packed = [packer.pack_conv_x3(w.astype(np.float64), np.zeros(coutg, np.float32)) for _ in range(groups)]
-            packed = [(q[0].view(np.float32), q[1]) for q in packed]
+            packed = [packer.pack_conv_x3([(w.astype(np.float64), np.zeros(coutg, np.float32)) for _ in range(groups)])]
         else:
             tr = (lambda t: t, packer.winograd_weights, packer.winograd2d_weights, None, packer.winograd24_weights,
                   packer.polyphase2_weights)[wino]
