@@ -678,7 +678,8 @@ def main():
         out = {'metric': 'frames/sec (2-hand mesh) at 512x512 batch-64; vertex L2 vs ref', 'value': round(fps, 2),
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': {'fp32': 'f32', 'fp16': 'f16 storage / f32 accumulate (NOT the headline precision)', 'bf16': 'bf16 storage / f32 accumulate (NOT the headline precision)'}[args.precision], 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
+               'dtype': {'fp32': 'f32', 'fp16': 'f16 storage / f32 accumulate (NOT the headline precision)', 'bf16': 'bf16 storage / f32 accumulate (NOT the headline precision)',
+                         'fp16x3': 'f32 storage, split f16 operands x3 on the 16-bit matrix pipe / f32 accumulate (NOT the headline arithmetic)'}[args.precision], 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
                'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, %s' % args.precision,
                           'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
                           'gather': (('rccl all-gather of result slots per batch, transport ' + runner.transport) if runner is not None else 'none (one rank)'),
