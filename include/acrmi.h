@@ -230,7 +230,13 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
  * 3 = Winograd F(2x2,3x3) with the layer's taps resident in LDS (groups 1, Cin <= 32, Cout = 32, H % 8 == 0,
  *     W % 16 == 0; w_packed = pack_wino3(w), 64 KiB);
  * 4 = Winograd F(2x4,3x3): F(2,3) along y, F(4,3) along x (3x3 stride 1, Cin > 32; w_packed =
- *     pack_conv(winograd24_weights(w)), 4x6 taps).
+ *     pack_conv(winograd24_weights(w)), 4x6 taps);
+ * 5 = 3x3 STRIDE 2 in polyphase form with F(2,2) on the two-tap phases (Cin % 16 == 0, Cout % 32 == 0, H % 16 == 0,
+ *     W % 32 == 0; w_packed = pack_conv(polyphase2_weights(w)), 4 waves x 7 taps; csrc/conv_pp2.inc);
+ * 6 = 3x3 stride 1 with SPLIT operands on the 16-bit matrix pipe: fp32 tensors, every operand split into f16 hi + lo
+ *     in registers, three products per MAC on v_mfma_f32_32x32x16_f16, fp32 accumulation (Cin % 32 == 0, Cout % 32 == 0,
+ *     H % 8 == 0, W % 32 == 0, |x| < 65504; w_packed = pack_conv_x3([(w, b)]): split f16 fragments of the filters scaled by
+ *     a power of two + one trailing float holding the inverse scale; csrc/conv_x3.inc).  The 'fp16x3' programs.
  * algo | ACRMI_CONV_BIAS_MAP (not with 3): res is ONE map [Ho][Wo][res_cs] added to every frame (see acrmi_op.flags). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,
