@@ -49,6 +49,36 @@ def test_head_maps_match_oracle(hip_maps, oracle_maps):
         assert err < 1e-4 * max(1.0, scale), (k, err, scale)      # fp32 re-association over ~60 conv layers
 
 
+def test_split_operand_program_matches_oracle_and_reference_golden(synth_sd, mano_tables, frames2, oracle_maps):
+    """The 'fp16x3' program (fp32 storage, conv_x3_kernel: split f16 operands, three products per MAC on the 16-bit matrix
+    pipe) under the SAME tolerances as the fp32 program: head maps against the oracle and against the reference's golden
+    vectors, detections and vertices against the reference's end-to-end fixture."""
+    L = pkg('_lib')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(synth_sd, max_batch=2, precision='fp16x3', wino24=True, splitk=False)
+    eng.load_mano(_flip_left(mano_tables))
+    assert sum(i.get('kernel') == 'conv_x3_kernel' for i in eng.program['op_info']) >= 190
+    B = eng.backbone_heads(torch.from_numpy(frames2).cuda())
+    torch.cuda.synchronize()
+    maps = {k: v.cpu() for k, v in eng.head_maps(B).items()}
+    for k in ('l_center_map', 'r_center_map', 'l_params_maps', 'r_params_maps', 'l_prior_maps', 'r_prior_maps', 'segms'):
+        a, b = maps[k], oracle_maps[k]
+        err = (a - b).abs().max().item()
+        assert err < 1e-4 * max(1.0, b.abs().max().item()), (k, err)
+    g = golden('net_frame0.npz')
+    for k in ('l_center_map', 'r_center_map'):
+        np.testing.assert_allclose(maps[k][:1].numpy(), g[k], rtol=1e-4, atol=1e-4)
+    ge = golden('e2e_batch1.npz')
+    out = eng.forward(torch.from_numpy(frames2).cuda())
+    torch.cuda.synchronize()
+    slots = out['slots'].cpu().numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(slots[b, :, L.SLOT_FLAG] > 0.5, ge['f%d_detection_flag' % b].astype(bool))
+        assert np.abs(out['verts'][b].cpu().numpy() - ge['f%d_verts' % b]).max() < 1e-4
+        assert np.abs(out['joints'][b].cpu().numpy() - ge['f%d_j3d' % b]).max() < 1e-4
+    eng.close()
+
+
 def test_head_maps_match_reference_golden(hip_maps):
     g = golden('net_frame0.npz')
     for k in ('l_center_map', 'r_center_map'):
