@@ -88,10 +88,10 @@ def validate(ns):
         raise ValueError('align_idx must be a joint index 0..20')
     if getattr(ns, 'batch_semantics', 'frame') not in ('frame', 'reference'):
         raise ValueError("batch_semantics %r: 'frame' or 'reference'" % (ns.batch_semantics,))
-    if ns.model_precision not in ('fp32', 'fp16', 'bf16', 'fp16x3'):
+    if ns.model_precision not in ('fp32', 'fp16', 'bf16', 'fp16x3', 'bf16x3'):
         # acr/config.py:96: fp32 (configs/demo.yml) | fp16 (the argparse default: autocast, acr/model.py:33-37);
         # bf16 = the same 16-bit program on the other gfx950 MFMA type (packer.lower)
-        raise ValueError("model_precision %r: 'fp32', 'fp16', 'bf16' or 'fp16x3'" % ns.model_precision)
+        raise ValueError("model_precision %r: 'fp32', 'fp16', 'bf16', 'fp16x3' or 'bf16x3'" % ns.model_precision)
     return ns
 
 

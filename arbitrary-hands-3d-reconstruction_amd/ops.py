@@ -45,9 +45,9 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     cout = cout_t // groups
     b = np.zeros(cout_t, np.float32) if bias is None else (
         bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
-    if algo == 'split16':
+    if algo in ('split16', 'split_bf16'):
         if k != 3 or stride != 1:
-            raise ValueError('the split-f16 kernel is for 3x3 stride-1 convolutions')
+            raise ValueError('the split-operand kernel is for 3x3 stride-1 convolutions')
         tr = None
     elif algo == 'polyphase2':
         if k != 3 or stride != 2:
@@ -60,14 +60,15 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     elif algo == 'direct':
         tr = lambda t: t
     else:
-        raise ValueError('algo must be "direct", "winograd", "winograd2d", "winograd2d_lds", "winograd24", "polyphase2" or "split16"')
-    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2, 'winograd2d_lds': 3, 'winograd24': 4, 'polyphase2': 5, 'split16': 6}[algo]
+        raise ValueError('algo must be "direct", "winograd", "winograd2d", "winograd2d_lds", "winograd24", "polyphase2", "split16" or "split_bf16"')
+    algo_id = {'direct': 0, 'winograd': 1, 'winograd2d': 2, 'winograd2d_lds': 3, 'winograd24': 4, 'polyphase2': 5, 'split16': 6, 'split_bf16': 7}[algo]
     if algo_id == 3:
         if groups != 1 or cout != 32 or cin_g > 32:
             raise ValueError('winograd2d_lds needs groups = 1, Cout = 32, Cin <= 32')
         packed = [pack_wino3(w.astype(np.float64), b)]
-    elif algo_id == 6:
-        packed = [pack_conv_x3([(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout]) for g in range(groups)])]
+    elif algo_id in (6, 7):
+        packed = [pack_conv_x3([(w[g * cout:(g + 1) * cout].astype(np.float64), b[g * cout:(g + 1) * cout]) for g in range(groups)],
+                               DT_BF16 if algo_id == 7 else DT_F16)]
     else:
         packed = [pack_conv(tr(w[g * cout:(g + 1) * cout].astype(np.float64)), b[g * cout:(g + 1) * cout])
                   for g in range(groups)]

@@ -75,8 +75,9 @@ def pack_conv(w, b):
 
 
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
-# 'fp16x3': fp32 storage, split-f16 operands on the 16-bit matrix pipe where conv_x3_kernel takes the layer (algo 6)
-PRECISIONS = {'fp32': DT_F32, 'fp16': DT_F16, 'bf16': DT_BF16, 'fp16x3': DT_F32}
+# 'fp16x3' / 'bf16x3': fp32 storage, split f16 / bf16 operands on the 16-bit matrix pipe where conv_x3_kernel takes the layer
+# (algo 6 / 7)
+PRECISIONS = {'fp32': DT_F32, 'fp16': DT_F16, 'bf16': DT_BF16, 'fp16x3': DT_F32, 'bf16x3': DT_F32}
 
 
 def round_to(x, dt):
@@ -323,11 +324,12 @@ def wino24b_width(cin, cout, ho, wo):
 
 def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, wino24=None, split16=False):
     """0 direct, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3), 3 F(2x2,3x3) with LDS-resident taps, 4 F(2x4,3x3),
-    5 polyphase F(2,2) (3x3 stride 2), 6 split-f16 operands on the 16-bit matrix pipe (split16 programs only).
+    5 polyphase F(2,2) (3x3 stride 2), 6 / 7 split f16 / bf16 operands on the 16-bit matrix pipe (split16 = True | 'fp16' / 'bf16':
+    the 'fp16x3' / 'bf16x3' programs only).
     wino24: None = WINOGRAD_24; False keeps the F(2x2,3x3) kernels for the layers F(2x4,3x3) would take (small batches:
     its 8x32-pixel, one-n-tile items are half as many as conv_wino2's small-batch items)."""
     if split16 and split16_ok(k, stride, cin, cout, ho, wo):
-        return 6
+        return 7 if split16 == 'bf16' else 6
     if k == 3 and stride == 2:
         big = WINOGRAD_24 if wino24 is None else wino24       # (the large-batch lowering: items of 8x16 output pixels)
         return 5 if (POLYPHASE2 and big and polyphase2_ok(cin, cout, ho, wo)) else 0
@@ -437,7 +439,7 @@ class Program(object):
         self.splitk = splitk      # small-batch program: split-K lowering of the low-resolution 3x3 layers
         self.pairs = pairs and dt == DT_F32      # large-batch fp32 program: layer1's conv3 / next conv1 pairs as one op
         self.wino24 = wino24      # None = packer.WINOGRAD_24
-        self.split16 = split16 and dt == DT_F32      # 'fp16x3' program
+        self.split16 = split16 if dt == DT_F32 else False      # 'fp16x3' / 'bf16x3' program (True | 'fp16' | 'bf16')
         self.keep_all = keep_all  # no lifetime-based buffer reuse: every intermediate map survives the run (tests)
         self.blob = Blob()
         self.bufs = []           # (h, w, cs, persistent, dtype)
@@ -557,8 +559,8 @@ class Program(object):
         else:
             algo = 2 if slices > 1 else conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24,
                                                     self.split16)
-            if algo == 6:
-                packed = [pack_conv_x3(wb_list)]                 # (one power-of-two weight scale for the op: trailing float)
+            if algo in (6, 7):
+                packed = [pack_conv_x3(wb_list, DT_BF16 if algo == 7 else DT_F16)]      # (one power-of-two weight scale for the op: trailing float)
             elif algo == 3:
                 packed = [pack_wino3(w, b) for (w, b) in wb_list]
             else:
@@ -579,14 +581,14 @@ class Program(object):
             self.ops[-1].flags = algo | _lib.CONV_BIAS_MAP
             self.ops[-1].w_off2 = self.blob.add(bias_map)
         self.op_info[-1]['algo'] = ('direct', 'winograd_f23x', 'winograd_f2x2_3x3', 'winograd_f2x2_3x3_lds',
-                                    'winograd_f2x4_3x3', 'polyphase_f2x2_s2', 'split_f16x3')[algo] + ('_splitk%d' % slices if slices > 1 else '')
+                                    'winograd_f2x4_3x3', 'polyphase_f2x2_s2', 'split_f16x3', 'split_bf16x3')[algo] + ('_splitk%d' % slices if slices > 1 else '')
         # what bench.py prints next to the PMC traffic: the kernel family launch_conv picks for this op (conv_mfma.hip /
         # conv_wino24b.inc wino24b_ok) and the op's ALGORITHMIC HBM bytes per frame - input slice + output (+ residual)
         # once, in their storage types
         ng = len(wb_list)
         esz = lambda b: 4 if self.dtype_of(b) == DT_F32 else 2
         fam = ('conv_ws2_kernel', 'conv_wino_kernel', 'conv_wino2_kernel', 'conv_wino3_kernel', 'conv_wino24_kernel',
-               'conv_pp2_kernel', 'conv_x3_kernel')[algo]
+               'conv_pp2_kernel', 'conv_x3_kernel', 'conv_x3_kernel')[algo]
         if algo == 4 and wino24b_width(cin, cout, ho, wo):
             fam = 'conv_wino24b_kernel'
         if self.dt != DT_F32:
@@ -790,7 +792,7 @@ def lower(sd, check=True, point_heads=True, keep_taps=False, precision='fp32', k
     dt = PRECISIONS[precision]
     point_heads = point_heads and dt == DT_F32 and width == 32     # (the point-heads kernels are fp32, 34-channel)
     P = Program(sd, dt, keep_weights, keep_all, wino24, splitk, FUSE_PAIRS and not splitk if pairs is None else pairs,
-                split16=precision == 'fp16x3')
+                split16={'fp16x3': 'fp16', 'bf16x3': 'bf16'}.get(precision, False))
     b = 'backbone.'
     taps = {}
     x34 = None

@@ -128,7 +128,7 @@ def parity(eng, oracle):
             'against': 'oracle/ (CPU fp32 restatement pinned to the reference) on the cpu_baseline sample frames'}
 
 
-def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16', 'bf16', 'fp16x3')):
+def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16', 'bf16', 'fp16x3', 'bf16x3')):
     """Reported NEXT TO the headline, never as it: the reference's --model_precision fp16 branch (acr/model.py:33-37) and
     its bf16 twin as 16-bit programs (packer.lower) on the same frames, same K steps, two contexts in turn like the
     headline; `parity` = against the fp32 oracle (what 16-bit storage costs), not against a 16-bit reference (none
@@ -172,8 +172,8 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
                                    bufs_[o.out_buf][0] * bufs_[o.out_buf][1] * o.cout * o.groups * esz(o.out_buf) *
                                    (2 if o.res_buf >= 0 else 1))
         r = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
-             'dtype': ('f32 storage; 3x3 stride-1 layers: operands split into f16 hi + lo, 3 products per MAC on '
-                       'v_mfma_f32_32x32x16_f16, f32 accumulate; other ops as the fp32 program' if prec == 'fp16x3' else
+             'dtype': ('f32 storage; 3x3 stride-1 layers: operands split into %s hi + lo, 3 products per MAC on '
+                       'v_mfma_f32_32x32x16_%s, f32 accumulate; other ops as the fp32 program' % ((prec[:-2],) * 2) if prec.endswith('x3') else
                        {'fp16': 'f16', 'bf16': 'bf16'}[prec] + ' storage, f32 accumulate (v_mfma_f32_32x32x16)'),
              'all_conv_ms_single_stream': round(conv_ms, 3), 'all_ops_ms_single_stream': round(total_ms, 3),
              'mfma_tflops_single_stream': round(flops / (total_ms * 1e-3) / 1e12, 1), 'mfma_peak_tflops': 2500.0,
@@ -189,7 +189,8 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
                    'accumulate / bias / residual / ReLU, one rounding per layer; stem, head exits, attention pooling, '
                    'decode, MANO fp32.  fp16x3: activations and weights stay fp32 in memory; conv_x3_kernel splits every '
                    'operand into two f16 numbers (22 bits) and multiplies on the 16-bit matrix pipe - the accuracy of the '
-                   'fp32 program at a higher rate.  parity is against the FP32 oracle.')
+                   'fp32 program at a higher rate; bf16x3: the same with bf16 halves (16 bits, fp32 exponent range).  '
+                   'parity is against the FP32 oracle.')
     return res
 
 
@@ -679,7 +680,8 @@ def main():
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': {'fp32': 'f32', 'fp16': 'f16 storage / f32 accumulate (NOT the headline precision)', 'bf16': 'bf16 storage / f32 accumulate (NOT the headline precision)',
-                         'fp16x3': 'f32 storage, split f16 operands x3 on the 16-bit matrix pipe / f32 accumulate (NOT the headline arithmetic)'}[args.precision], 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
+                         'fp16x3': 'f32 storage, split f16 operands x3 on the 16-bit matrix pipe / f32 accumulate (NOT the headline arithmetic)',
+                         'bf16x3': 'f32 storage, split bf16 operands x3 on the 16-bit matrix pipe / f32 accumulate (NOT the headline arithmetic)'}[args.precision], 'data': 'synthetic (seeded random uint8 frames, synthetic checkpoint + MANO tables)',
                'config': {'workload': 'configs[2]: synthetic 512x512 RGB batch=64 per GPU, HRNet-W32 backbone, %s' % args.precision,
                           'frames_per_gpu': B, 'global_batch': B * world, 'parallelism': 'frame-sharded x%d' % world,
                           'gather': (('rccl all-gather of result slots per batch, transport ' + runner.transport) if runner is not None else 'none (one rank)'),

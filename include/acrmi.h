@@ -113,7 +113,7 @@ typedef struct {
   int32_t nterms;                         /* FUSESUM */
   int32_t term_buf[4], term_coff[4], term_shift[4];
   int64_t w_off2, b_off2, w_off3;         /* PAREBIAS: linear weights/bias, mix-conv pare columns */
-  int32_t flags;                          /* CONV: algo (bits 0-2) | ACRMI_CONV_BIAS_MAP; PAREBIAS: part slice start
+  int32_t flags;                          /* CONV: algo 0..7 (bits 0-2) | ACRMI_CONV_BIAS_MAP; PAREBIAS: part slice start
                                              (0 right / 16 left); POINTHEADS: side (0 left / 1 right) */
   int32_t mode;                           /* ACRMI_MODE_*                                    */
 } acrmi_op;
@@ -236,7 +236,9 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
  * 6 = 3x3 stride 1 with SPLIT operands on the 16-bit matrix pipe: fp32 tensors, every operand split into f16 hi + lo
  *     in registers, three products per MAC on v_mfma_f32_32x32x16_f16, fp32 accumulation (Cin % 32 == 0, Cout % 32 == 0,
  *     H % 8 == 0, W % 32 == 0, |x| < 65504; w_packed = pack_conv_x3([(w, b)]): split f16 fragments of the filters scaled by
- *     a power of two + one trailing float holding the inverse scale; csrc/conv_x3.inc).  The 'fp16x3' programs.
+ *     a power of two + one trailing float holding the inverse scale; csrc/conv_x3.inc).  The 'fp16x3' programs;
+ * 7 = the same with bf16 halves (v_mfma_f32_32x32x16_bf16; 16-bit operands, fp32's exponent range: no |x| limit;
+ *     w_packed = pack_conv_x3([(w, b)], DT_BF16)).  The 'bf16x3' programs.
  * algo | ACRMI_CONV_BIAS_MAP (not with 3): res is ONE map [Ho][Wo][res_cs] added to every frame (see acrmi_op.flags). */
 int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, int cin, const float* w_packed,
                  const float* bias, int bias_frame_stride, const float* res, int res_cs, int res_coff,

@@ -137,7 +137,8 @@ def test_hostile_checkpoint_against_the_reference_and_per_layer_winograd_error(m
     eng.close()
 
 
-def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
+@pytest.mark.parametrize('precision', ['fp16x3', 'bf16x3'])
+def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2, precision):
     """The 'fp16x3' program (fp32 storage; the 3x3 stride-1 layers on conv_x3_kernel: operands split into f16 hi + lo, three
     products per MAC on the 16-bit matrix pipe, fp32 accumulation) on the hostile checkpoint: (1) end to end against the
     real reference (e2e_batch1.npz) - decisions identical, vertices / joints inside the 1e-4 m budget of the fp32 program;
@@ -147,7 +148,8 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
     L = pkg('_lib')
     hs = synth.make_state_dict(seed=0, law='hostile')
     eng = pkg('engine').Engine(0)
-    eng.load_state_dict(hs, max_batch=2, keep_weights=True, keep_all=True, wino24=True, splitk=False, precision='fp16x3')
+    eng.load_state_dict(hs, max_batch=2, keep_weights=True, keep_all=True, wino24=True, splitk=False, precision=precision)
+    tol_v, tol_layer = (1e-5, 5e-6) if precision == 'fp16x3' else (2e-5, 1e-4)      # (bf16 halves: 16-bit operands; measured 2.4e-6 m, 2.0e-5)
     eng.load_mano(_flip_left(mano_tables))
     g = golden('e2e_batch1.npz')
     x = torch.from_numpy(frames2)
@@ -161,7 +163,7 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
         assert slots[b, 0, L.SLOT_FLATIND] == lc[1] * 64 + lc[0] and slots[b, 1, L.SLOT_FLATIND] == rc[1] * 64 + rc[0]
         worst_v = max(worst_v, float(np.abs(out['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max()),
                       float(np.abs(out['joints'][b].cpu().numpy() - g['f%d_j3d' % b]).max()))
-    assert worst_v < 1e-5, worst_v      # (measured 3.7e-7 m; the fp32 program: 2.9e-7 m)
+    assert worst_v < tol_v, worst_v      # (fp16x3 measured 3.7e-7 m; the fp32 program: 2.9e-7 m)
     prog = eng.program
     B = 1
     eng.backbone_heads(x[:1].cuda())
@@ -171,7 +173,7 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
     it.bufs = [b.clone() for b in hip]
     rows = []
     for i, (op, info) in enumerate(zip(prog['ops'], prog['op_info'])):
-        if op.mode == oprog.MODE_POINT or op.kind != oprog.OP_CONV or op.res_buf == op.out_buf or info.get('algo') != 'split_f16x3':
+        if op.mode == oprog.MODE_POINT or op.kind != oprog.OP_CONV or op.res_buf == op.out_buf or not str(info.get('algo')).startswith('split_'):
             continue
         later_in_place = any(o.kind == oprog.OP_CONV and o.res_buf == o.out_buf and o.out_buf == op.out_buf
                              for o in prog['ops'][i + 1:]) or any(o.kind == oprog.OP_POW11 and o.out_buf == op.out_buf
@@ -189,10 +191,10 @@ def test_split_operand_program_on_the_hostile_checkpoint(mano_tables, frames2):
     rows.sort(key=lambda r: -r['rel_err'])
     rep = {'end_to_end_max_vertex_joint_abs_err_m': worst_v, 'split_operand_layers': len(rows),
            'worst_rel_err': rows[0]['rel_err'], 'max_activation': max(r['in_absmax'] for r in rows), 'worst_layers': rows[:5]}
-    _report('hostile_checkpoint_fp16x3', rep)
+    _report('hostile_checkpoint_' + precision, rep)
     assert len(rows) >= 150
-    assert rep['max_activation'] < 65504.0          # the f16 range the split needs
-    assert rep['worst_rel_err'] < 5e-6, rep      # (measured 1.5e-6; F(2x4,3x3) on the fp32 pipe: 1.2e-6)
+    assert precision != 'fp16x3' or rep['max_activation'] < 65504.0          # the f16 range the split needs
+    assert rep['worst_rel_err'] < tol_layer, rep      # (fp16x3 measured 1.5e-6; F(2x4,3x3) on the fp32 pipe: 1.2e-6)
     eng.close()
 
 

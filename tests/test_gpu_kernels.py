@@ -326,7 +326,7 @@ def test_conv2d_split_f16_operands(ops, case):
     xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
     xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
     errs = {}
-    for algo in ('split16', 'winograd2d'):
+    for algo in ('split16', 'split_bf16', 'winograd2d'):
         dst = torch.full((B, H, W, cout + 16), 7.0, device='cuda')     # output into channels 8..
         ops.conv2d(xin, w, None if use_fb else b, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo=algo,
                    out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
@@ -337,6 +337,7 @@ def test_conv2d_split_f16_operands(ops, case):
         assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), algo
     assert errs['split16'] < 2e-5, errs
     assert errs['split16'] < 4 * errs['winograd2d'] + 1e-6, errs
+    assert errs['split_bf16'] < 5e-4, errs      # 16-bit operands: 2^-16 relative per product
 
 
 WINO3_CASES = [

@@ -306,6 +306,7 @@ def test_split16_and_pack_conv_x3_layout():
         assert abs(arr[ky, kx, s, n, 0, kgp, j, e] + arr[ky, kx, s, n, 1, kgp, j, e] - want) <= 2.0 ** -22 * abs(want)    # (scaled: no subnormal lo)
     np.testing.assert_array_equal(bp[:40], b.astype(np.float32))
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16=True) == 6 and packer.conv_algo(3, 1, 64, 64, 1, 64, 64) == 4
+    assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16='bf16') == 7
     assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 4 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2
 
 

@@ -19,7 +19,7 @@ sd = synth.make_state_dict(seed=0)
 tables = synth.make_mano_tables(seed=1)
 frames = torch.from_numpy(synth.make_frames(B, seed=0, structured=False)).cuda()
 res = {}
-for prec in ('fp32', 'fp16x3'):
+for prec in ('fp32', 'fp16x3', 'bf16x3'):
     eng = engine.Engine(0)
     eng.load_state_dict(sd, max_batch=B, precision=prec)
     eng.load_mano(tables)
@@ -50,11 +50,12 @@ for prec in ('fp32', 'fp16x3'):
     print('   ' + ', '.join('%s x%d %.2f ms' % (k_, v_[0], v_[1]) for k_, v_ in sorted(fam.items(), key=lambda kv: -kv[1][1])), flush=True)
     res[prec] = {k: v.cpu().numpy().copy() for k, v in views.items()}
     eng.close() if hasattr(eng, 'close') else None
-a, b = res['fp32'], res['fp16x3']
-flag_a, flag_b = a['slots'][..., L.SLOT_FLAG] > 0.5, b['slots'][..., L.SLOT_FLAG] > 0.5
-same = (flag_a == flag_b) & (~flag_a | (a['slots'][..., L.SLOT_FLATIND] == b['slots'][..., L.SLOT_FLATIND]))
-use = same & flag_a
-dv = np.linalg.norm(a['verts'] - b['verts'], axis=-1)[use]
-dj = np.linalg.norm(a['joints'] - b['joints'], axis=-1)[use]
-print('fp16x3 vs fp32 program: decisions differing %d, hands compared %d, max vertex distance %.3e m, max joint distance %.3e m' % (
-    int((~same).sum()), int(use.sum()), dv.max() if dv.size else -1, dj.max() if dj.size else -1))
+for other in ('fp16x3', 'bf16x3'):
+    a, b = res['fp32'], res[other]
+    flag_a, flag_b = a['slots'][..., L.SLOT_FLAG] > 0.5, b['slots'][..., L.SLOT_FLAG] > 0.5
+    same = (flag_a == flag_b) & (~flag_a | (a['slots'][..., L.SLOT_FLATIND] == b['slots'][..., L.SLOT_FLATIND]))
+    use = same & flag_a
+    dv = np.linalg.norm(a['verts'] - b['verts'], axis=-1)[use]
+    dj = np.linalg.norm(a['joints'] - b['joints'], axis=-1)[use]
+    print('%s vs fp32 program: decisions differing %d, hands compared %d, max vertex distance %.3e m, max joint distance %.3e m' % (
+        other, int((~same).sum()), int(use.sum()), dv.max() if dv.size else -1, dj.max() if dj.size else -1))
