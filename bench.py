@@ -311,6 +311,8 @@ def other_configs(tables, steps, warmup, local_rank):
     synth = pkg('synth')
     res = {}
     for name, width, prec, B, mano16 in (('configs[1] resnet50 bf16 batch32', 'resnet50', 'bf16', 32, False),
+                                          ('configs[1] resnet50 bf16x3 batch32 (bf16 ARITHMETIC on fp32 tensors: split operands, csrc/conv_x3.inc)',
+                                           'resnet50', 'bf16x3', 32, False),
                                           ('configs[4] hrnet_w48 fp16 batch64 fp16-mano', 48, 'fp16', 64, True)):
         sd = synth.make_state_dict(seed=0, width=width)
         frames = torch.from_numpy(synth.make_frames(B, seed=0, structured=False)).cuda()
