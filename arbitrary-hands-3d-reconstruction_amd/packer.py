@@ -288,8 +288,10 @@ def polyphase2_ok(cin, cout, ho, wo):
 # Split-operand 16-bit program ('fp16x3': fp32 storage, every operand of the eligible convolutions split into two f16
 # numbers, three products per MAC on the 16-bit matrix pipe with fp32 accumulation - csrc/conv_x3.inc, algo 6).
 def split16_ok(k, stride, cin, cout, ho, wo):
-    """conv_x3_kernel takes the layer (csrc/conv_x3.inc x3_ok)."""
-    return k == 3 and stride == 1 and cin % 32 == 0 and cin >= 32 and cout % 32 == 0 and ho % 8 == 0 and wo % 32 == 0
+    """conv_x3_kernel (3x3) / conv_x3p_kernel (1x1) takes the layer (csrc/conv_x3.inc x3_ok, conv_x3p.inc x3p_ok)."""
+    if not (stride == 1 and cin % 32 == 0 and cin >= 32 and cout % 32 == 0):
+        return False
+    return (k == 3 and ho % 8 == 0 and wo % 32 == 0) or (k == 1 and ho * wo > 0 and (ho * wo) % 256 == 0)
 
 
 def use_winograd(k, stride):
@@ -591,6 +593,8 @@ class Program(object):
                'conv_pp2_kernel', 'conv_x3_kernel', 'conv_x3_kernel')[algo]
         if algo == 4 and wino24b_width(cin, cout, ho, wo):
             fam = 'conv_wino24b_kernel'
+        if algo in (6, 7) and k == 1:
+            fam = 'conv_x3p_kernel'
         if self.dt != DT_F32:
             fam = 'conv_h16_kernel'
         self.op_info[-1]['kernel'] = fam

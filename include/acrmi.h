@@ -233,7 +233,7 @@ int acrmi_forward(acrmi_ctx* ctx, const uint8_t* img_dev, int B, const float* of
  *     pack_conv(winograd24_weights(w)), 4x6 taps);
  * 5 = 3x3 STRIDE 2 in polyphase form with F(2,2) on the two-tap phases (Cin % 16 == 0, Cout % 32 == 0, H % 16 == 0,
  *     W % 32 == 0; w_packed = pack_conv(polyphase2_weights(w)), 4 waves x 7 taps; csrc/conv_pp2.inc);
- * 6 = 3x3 stride 1 with SPLIT operands on the 16-bit matrix pipe: fp32 tensors, every operand split into f16 hi + lo
+ * 6 = 3x3 stride 1 (or 1x1 stride 1 with H W % 256 == 0: csrc/conv_x3p.inc) with SPLIT operands on the 16-bit matrix pipe: fp32 tensors, every operand split into f16 hi + lo
  *     in registers, three products per MAC on v_mfma_f32_32x32x16_f16, fp32 accumulation (Cin % 32 == 0, Cout % 32 == 0,
  *     H % 8 == 0, W % 32 == 0, |x| < 65504; w_packed = pack_conv_x3([(w, b)]): split f16 fragments of the filters scaled by
  *     a power of two + one trailing float holding the inverse scale; csrc/conv_x3.inc).  The 'fp16x3' programs;

@@ -340,6 +340,51 @@ def test_conv2d_split_f16_operands(ops, case):
     assert errs['split_bf16'] < 5e-4, errs      # 16-bit operands: 2^-16 relative per product
 
 
+X3P_CASES = [
+    # (B, Cin, Cout, H, W, groups, relu, residual kind: 0 none / 1 per frame, frame_bias)
+    (2, 64, 256, 16, 16, 1, True, 1, False),       # one item per frame, four n-blocks (layer1's conv3: residual + ReLU)
+    (20, 256, 64, 32, 32, 1, True, 0, False),      # 8 chunks; more items than workgroups can hold at once
+    (3, 32, 32, 16, 32, 1, False, 0, True),        # single-chunk items, one n-tile per wave, per-frame bias rows
+    (2, 96, 128, 16, 16, 1, True, 1, False),       # three chunks
+    (1, 128, 192, 32, 64, 2, False, 0, False),     # two groups of 64 -> 96 (one n-tile per wave, three n-blocks each)
+]
+
+
+@pytest.mark.parametrize('case', X3P_CASES, ids=lambda c: 'x3p_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv1x1_split_operands(ops, case):
+    """conv_x3p_kernel (1x1, fp32 storage, operands split into f16 / bf16 hi + lo, three products per MAC on the 16-bit matrix
+    pipe) vs an fp64 convolution and vs the fp32 direct kernel; channel slices of wider buffers, neighbours untouched."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 270)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 1, 1, generator=g) / np.sqrt(cin // groups)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 1, 0, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B, cout, H, W), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    errs = {}
+    for algo in ('split16', 'split_bf16', 'direct'):
+        dst = torch.full((B, H, W, cout + 16), 7.0, device='cuda')     # output into channels 8..
+        ops.conv2d(xin, w, None if use_fb else b, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo=algo,
+                   out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                   frame_bias=None if fb is None else fb.cuda())
+        torch.cuda.synchronize()
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        errs[algo] = (got.double() - ref).abs().max().item()
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), algo
+    assert errs['split16'] < 2e-5 and errs['split16'] < 4 * errs['direct'] + 2e-6, errs
+    assert errs['split_bf16'] < 5e-4, errs
+
+
 WINO3_CASES = [
     # B, Cin, H, W, relu, residual
     (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)

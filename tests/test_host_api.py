@@ -307,11 +307,13 @@ def test_split16_and_pack_conv_x3_layout():
     np.testing.assert_array_equal(bp[:40], b.astype(np.float32))
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16=True) == 6 and packer.conv_algo(3, 1, 64, 64, 1, 64, 64) == 4
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16='bf16') == 7
+    assert packer.conv_algo(1, 1, 256, 64, 1, 128, 128, split16=True) == 6 and packer.conv_algo(1, 1, 256, 64, 1, 128, 128) == 0
+    assert packer.conv_algo(1, 1, 256, 64, 1, 10, 10, split16=True) == 0 and packer.conv_algo(1, 2, 256, 64, 1, 64, 64, split16=True) == 0
     assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 4 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2
 
 
 def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
-    """'fp16x3' lowers to the SAME op list, buffers and biases as 'fp32' - only the eligible 3x3 stride-1 convolutions
+    """'fp16x3' lowers to the SAME op list, buffers and biases as 'fp32' - only the eligible 3x3 and 1x1 stride-1 convolutions
     change their kernel (algo 6) and weight packing."""
     packer, L = pkg('packer'), pkg('_lib')
     p32 = packer.lower(synth_sd, precision='fp32', point_heads=False)
@@ -323,7 +325,7 @@ def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
             b.kind, b.in_buf, b.out_buf, b.res_buf, b.cin, b.cout, b.ksize, b.stride, b.groups)
         if b.kind == L.OP_CONV and (b.flags & 7) == 6:
             n6 += 1
-            assert (a.flags & 7) in (3, 4) and b.ksize == 3 and b.stride == 1
+            assert b.stride == 1 and ((b.ksize == 3 and (a.flags & 7) in (3, 4)) or (b.ksize == 1 and (a.flags & 7) == 0))
         else:
             assert a.flags == b.flags
     assert n6 >= 190

@@ -35,6 +35,9 @@ SHAPES = [
     ('segm 256->32 3x3 @128', 256, 32, 128, 128, 3, 1, 1, False),
     ('l1 64->256 1x1 @128', 64, 256, 128, 128, 1, 1, 1, True),
     ('l1 256->64 1x1 @128', 256, 64, 128, 128, 1, 1, 1, False),
+    ('r50 1024->256 1x1 @32', 1024, 256, 32, 32, 1, 1, 1, False),
+    ('r50 256->1024 1x1 @32', 256, 1024, 32, 32, 1, 1, 1, True),
+    ('fuse 128->32 1x1 @32', 128, 32, 32, 32, 1, 1, 1, False),
     ('s2 64->64 3x3s2 @256', 64, 64, 256, 256, 3, 2, 1, False),
     ('s2 256->64 3x3s2 @128', 256, 64, 128, 128, 3, 2, 1, False),
     ('entry 34->512 3x3s2 @128', 34, 512, 128, 128, 3, 2, 1, False),
