@@ -532,6 +532,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 #include "conv_pp2.inc"
 #include "conv_x3.inc"
 #include "conv_x3p.inc"
+#include "conv_p1.inc"
 
 // Tile selection.  N32: one 32-cout tile per wave (Cout <= 32); N64: two.
 // Small frames (<=16x16 outputs) take the 8x16 pixel tile so a batch still fills 256 CUs.
@@ -627,6 +628,11 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     return launch_conv(b, s);
   }
   if (a.ks == 1 && a.stride == 1) {
+    // the four-wave streaming frame (conv_p1.inc) wherever its 256-pixel x 64-cout items fill the chip (large batches);
+    // conv_bench --cfg 809 keeps the eight-wave kernels (A/B)
+    if (p1_ok(a) && g_force_cfg != 809 &&
+        (long)((a.Ho * a.Wo) / 256) * a.B * a.groups * ((a.Cout / 32) / (a.Cout % 64 == 0 ? 2 : 1)) >= cus)
+      return launch_p1(a, s);
     if (n32) return (small || (fine && tiles16 < cus)) ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s)
                                                         : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);
     // (a short contraction writing many channels - layer1's 64 -> 256 + residual - is latency-bound on one or two

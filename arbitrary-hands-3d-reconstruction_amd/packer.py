@@ -595,6 +595,9 @@ class Program(object):
             fam = 'conv_wino24b_kernel'
         if algo in (6, 7) and k == 1:
             fam = 'conv_x3p_kernel'
+        if (algo == 0 and k == 1 and stride == 1 and cin % 32 == 0 and cout % 32 == 0 and (ho * wo) % 256 == 0 and
+                (WINOGRAD_24 if self.wino24 is None else self.wino24)):
+            fam = 'conv_p1_kernel'       # (large batches: conv_mfma.hip launch_conv routes these to the streaming frame, conv_p1.inc)
         if self.dt != DT_F32:
             fam = 'conv_h16_kernel'
         self.op_info[-1]['kernel'] = fam

@@ -385,6 +385,57 @@ def test_conv1x1_split_operands(ops, case):
     assert errs['split_bf16'] < 5e-4, errs
 
 
+P1_CASES = [
+    # (B, Cin, Cout, H, W, groups, relu, residual kind, frame_bias) - enough 256-pixel x 64-cout items to fill 256 CUs
+    (8, 64, 256, 64, 64, 1, True, 1, False),       # layer1's conv3: two chunks, four n-blocks, residual + ReLU
+    (16, 256, 64, 64, 64, 1, True, 0, False),      # eight chunks
+    (40, 32, 32, 32, 64, 1, False, 0, True),       # single-chunk items, one n-tile per wave, per-frame bias rows
+    (12, 96, 128, 32, 32, 1, True, 1, False),      # three chunks
+    (10, 128, 192, 32, 64, 2, False, 0, False),    # two groups of 64 -> 96 (one n-tile per wave)
+]
+
+
+@pytest.mark.parametrize('case', P1_CASES, ids=lambda c: 'p1_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv1x1_streaming_frame(ops, case):
+    """conv_p1_kernel (fp32 1x1 on the four-wave streaming frame: register-staged loads one chunk ahead, fp32 planes in LDS, one
+    barrier per chunk) vs an fp64 convolution and vs the eight-wave direct kernel (acrmi_tune cfg 809 keeps it)."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    L = pkg('_lib').lib()
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 280)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 1, 1, generator=g) / np.sqrt(cin // groups)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 1, 0, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B, cout, H, W), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    outs = {}
+    for cfg in (-1, 809):
+        dst = torch.full((B, H, W, cout + 16), 7.0, device='cuda')     # output into channels 8..
+        L.acrmi_tune(0, cfg)
+        try:
+            ops.conv2d(xin, w, None if use_fb else b, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo='direct',
+                       out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                       frame_bias=None if fb is None else fb.cuda())
+            torch.cuda.synchronize()
+        finally:
+            L.acrmi_tune(0, -1)
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        err = (got.double() - ref).abs().max().item()
+        assert err < 1e-4, (cfg, err)
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), cfg
+        outs[cfg] = got
+    assert (outs[-1] - outs[809]).abs().max().item() < 2e-5      # (different accumulation orders of the same fp32 products)
+
+
 WINO3_CASES = [
     # B, Cin, H, W, relu, residual
     (2, 32, 16, 32, True, True),         # HRNet branch 0 shape class: BasicBlock conv2 (residual + ReLU)
