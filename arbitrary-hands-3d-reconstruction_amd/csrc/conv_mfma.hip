@@ -628,10 +628,11 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     return launch_conv(b, s);
   }
   if (a.ks == 1 && a.stride == 1) {
-    // the four-wave streaming frame (conv_p1.inc) wherever its 256-pixel x 64-cout items fill the chip (large batches);
+    // the four-wave streaming frame (conv_p1.inc) wherever its 256-pixel x 64-cout items fill the chip twice (large batches;
+    // a single frame's 64 -> 256 @128^2 is exactly 256 items: one per CU is slower than the finer items below);
     // conv_bench --cfg 809 keeps the eight-wave kernels (A/B)
     if (p1_ok(a) && g_force_cfg != 809 &&
-        (long)((a.Ho * a.Wo) / 256) * a.B * a.groups * ((a.Cout / 32) / (a.Cout % 64 == 0 ? 2 : 1)) >= cus)
+        (long)((a.Ho * a.Wo) / 256) * a.B * a.groups * ((a.Cout / 32) / (a.Cout % 64 == 0 ? 2 : 1)) >= 2 * cus)
       return launch_p1(a, s);
     if (n32) return (small || (fine && tiles16 < cus)) ? launch_ws2<1, 1, 8, 16, 4, 1, 1, 1, 64, 2>(a, s)
                                                         : launch_ws2<1, 1, 16, 16, 4, 2, 1, 1, 64, 4>(a, s);

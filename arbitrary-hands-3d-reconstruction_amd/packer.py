@@ -596,8 +596,11 @@ class Program(object):
         if algo in (6, 7) and k == 1:
             fam = 'conv_x3p_kernel'
         if (algo == 0 and k == 1 and stride == 1 and cin % 32 == 0 and cout % 32 == 0 and (ho * wo) % 256 == 0 and
-                (WINOGRAD_24 if self.wino24 is None else self.wino24)):
-            fam = 'conv_p1_kernel'       # (large batches: conv_mfma.hip launch_conv routes these to the streaming frame, conv_p1.inc)
+                (WINOGRAD_24 if self.wino24 is None else self.wino24) and
+                (ho * wo // 256) * 64 * ng * ((cout // 32) // (2 if cout % 64 == 0 else 1)) >= 512):
+            # (batch 64 on 256 CUs: conv_mfma.hip launch_conv routes the layer to the streaming frame, conv_p1.inc, when its
+            #  items fill the chip twice)
+            fam = 'conv_p1_kernel'
         if self.dt != DT_F32:
             fam = 'conv_h16_kernel'
         self.op_info[-1]['kernel'] = fam
