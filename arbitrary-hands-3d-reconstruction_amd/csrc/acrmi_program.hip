@@ -402,8 +402,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       if (algo == 4 && (op.cin < 32 || (op.cin == 32 && (op.cout % 32 || ho % 8 || wo % 32))))      // (Cin = 32: conv_wino24b_kernel only)
         return fail(c, ACRMI_EINVAL, "op %d: algo 4 needs Cin > 32, or Cin = 32 with Cout %% 32 = 0 on a map of 8x32-pixel tiles", i);
       if ((algo == 6 || algo == 7) && (idt || op.cin % 32 || op.cout % 32 || op.out_coff % 4 || op.res_coff % 4 ||
-                                       (op.ksize == 3 ? (ho % 8 || wo % 32) : ((ho * wo) % 256 != 0))))      // (conv_x3.inc x3_ok / conv_x3p.inc x3p_ok)
-        return fail(c, ACRMI_EINVAL, "op %d: algo 6 / 7 needs fp32 storage, Cin %% 32 = 0, Cout %% 32 = 0, a map of 8x32-pixel tiles (3x3) / of whole 256-pixel items (1x1)", i);
+                                       (op.ksize == 3 ? ((ho % 8 || wo % 32) && (ho % 16 || wo % 16)) : ((ho * wo) % 256 != 0))))      // (conv_x3.inc x3_ok / conv_x3p.inc x3p_ok)
+        return fail(c, ACRMI_EINVAL, "op %d: algo 6 / 7 needs fp32 storage, Cin %% 32 = 0, Cout %% 32 = 0, a map of 8x32- or 16x16-pixel tiles (3x3) / of whole 256-pixel items (1x1)", i);
       if (algo == 5 && (idt || op.cin % 16 || op.cout % 32 || bufs[op.in_buf].h % 2 || bufs[op.in_buf].w % 2 || ho % 8 || wo % 16 ||
                         op.out_coff % 4 || op.res_coff % 4))      // (conv_pp2.inc pp2_ok)
         return fail(c, ACRMI_EINVAL, "op %d: algo 5 needs fp32, Cin %% 16 = 0, Cout %% 32 = 0, an output map of 8x16-pixel tiles", i);

@@ -291,7 +291,8 @@ def split16_ok(k, stride, cin, cout, ho, wo):
     """conv_x3_kernel (3x3) / conv_x3p_kernel (1x1) takes the layer (csrc/conv_x3.inc x3_ok, conv_x3p.inc x3p_ok)."""
     if not (stride == 1 and cin % 32 == 0 and cin >= 32 and cout % 32 == 0):
         return False
-    return (k == 3 and ho % 8 == 0 and wo % 32 == 0) or (k == 1 and ho * wo > 0 and (ho * wo) % 256 == 0)
+    return (k == 3 and ((ho % 8 == 0 and wo % 32 == 0) or (ho % 16 == 0 and wo % 16 == 0))) or (
+        k == 1 and ho * wo > 0 and (ho * wo) % 256 == 0)
 
 
 def use_winograd(k, stride):

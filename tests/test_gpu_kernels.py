@@ -300,6 +300,9 @@ X3_CASES = [
     (3, 32, 256, 32, 64, 1, True, 2, False),       # single-chunk items (Cin = 32): the contact conv + its bias map
     (2, 256, 32, 32, 64, 1, True, 1, False),       # one n-tile per wave (Cout = 32), 8 chunks
     (3, 32, 32, 24, 64, 1, True, 1, False),        # single chunk AND one n-tile (HRNet branch 0)
+    (3, 256, 256, 16, 16, 1, True, 1, False),      # HRNet branch 3: the 16x16-pixel items, one per frame and n-block, 8 chunks
+    (2, 64, 128, 32, 16, 1, True, 0, False),       # ... two tiles per frame (top / bottom borders differ)
+    (2, 64, 32, 16, 48, 1, False, 2, True),        # ... three tile columns (an interior one), one n-tile per wave, map residual + frame bias
 ]
 
 

@@ -309,7 +309,8 @@ def test_split16_and_pack_conv_x3_layout():
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16='bf16') == 7
     assert packer.conv_algo(1, 1, 256, 64, 1, 128, 128, split16=True) == 6 and packer.conv_algo(1, 1, 256, 64, 1, 128, 128) == 0
     assert packer.conv_algo(1, 1, 256, 64, 1, 10, 10, split16=True) == 0 and packer.conv_algo(1, 2, 256, 64, 1, 64, 64, split16=True) == 0
-    assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 4 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2
+    assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 6 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2
+    assert packer.conv_algo(3, 1, 64, 64, 1, 24, 16, split16=True) == 2
 
 
 def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
