@@ -305,6 +305,10 @@ def test_split16_and_pack_conv_x3_layout():
         want = w[co, ci, ky, kx] if co < 40 else 0.0
         assert abs(arr[ky, kx, s, n, 0, kgp, j, e] + arr[ky, kx, s, n, 1, kgp, j, e] - want) <= 2.0 ** -22 * abs(want)    # (scaled: no subnormal lo)
     np.testing.assert_array_equal(bp[:40], b.astype(np.float32))
+    # the weight scale: zero / non-finite filters fall back to no scaling; grouped ops share ONE scale (the largest group decides)
+    assert packer.x3_weight_shift([np.zeros((32, 32, 3, 3))]) == 0 and packer.x3_weight_shift([np.full((32, 32, 1, 1), np.inf)]) == 0
+    pg, bg = packer.pack_conv_x3([(w[:32], b[:32]), (w[:32] * 2.0 ** -6, b[:32])], packer.DT_BF16)
+    assert pg.size == 2 * 9 * (32 // 8) * 256 + 1 and pg[-1] == np.float32(2.0 ** -packer.x3_weight_shift([w[:32]])) and bg.size == 64
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16=True) == 6 and packer.conv_algo(3, 1, 64, 64, 1, 64, 64) == 4
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16='bf16') == 7
     assert packer.conv_algo(1, 1, 256, 64, 1, 128, 128, split16=True) == 6 and packer.conv_algo(1, 1, 256, 64, 1, 128, 128) == 0
