@@ -2,8 +2,9 @@
 """ACR hot-path benchmark: frames/s (2-hand mesh) at 512x512, batch 64 per GPU, HRNet-W32 fp32.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (spawns its own N ranks: one process per GPU over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          (the driver's form: ranks already exist)
 
 A step = one pass of the whole path (uint8 frames resident in HBM -> backbone -> heads -> decode ->
 MANO -> verts/joints, plus for N>1 the RCCL all-gather of every rank's result slots) over one batch of
@@ -520,6 +521,96 @@ def run_pipelined(n, frames, eng=None, pool=None, runner=None, vsets=None):
     return last
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): re-executes this file under
+    torch.distributed.run with one rank per GPU on 127.0.0.1 and a free port (the reference's counterpart is the
+    single-process nn.DataParallel of acr/main.py:61).  Rank 0's JSON line stays the last line of stdout: the children
+    inherit it.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (RCCL between processes)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class StandInEngine(object):
+    """CPU stand-in for engine.Engine behind `--standin` (tests/test_parallel_gloo.py: `bench.py --gpus 2` end to end over
+    gloo on a box without GPUs).  NOT a model and not the oracle: slots / verts / joints are cheap deterministic
+    functions of the frame bytes, enough to check that every rank ends with every rank's rows in frame order.  The line a
+    stand-in run prints says so in `metric` and `data`; it is never a measurement."""
+    device = torch.device('cpu')
+    comm_ranks = 0
+
+    @staticmethod
+    def fill(frames, out):
+        f = frames.reshape(frames.shape[0], -1).to(torch.float32)
+        key = torch.stack([f.mean(1), f[:, ::4099].sum(1) / 1e3], 1)          # [n, 2]
+        out['slots'].copy_(key[:, :, None].expand(-1, -1, out['slots'].shape[2]))
+        out['verts'].copy_((key[:, :, None, None] + torch.arange(778.)[None, None, :, None] * 1e-3).expand(-1, -1, -1, 3))
+        out['joints'].copy_((key[:, :, None, None] - torch.arange(21.)[None, None, :, None] * 1e-3).expand(-1, -1, -1, 3))
+
+    def forward(self, frames, out=None):
+        self.fill(frames, out)
+        return out
+
+
+def standin_main(args, rank, world):
+    """bench.py's N > 1 wiring (process group, ShardedRunner, run_pipelined, barriers, MAX over ranks, one JSON line on rank
+    0) with StandInEngine on the CPU over gloo."""
+    import torch.distributed as dist
+    parallel, synth = pkg('parallel'), pkg('synth')
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    B = args.batch
+    frames = torch.from_numpy(synth.make_frames(B, seed=rank, structured=False))
+    eng = StandInEngine()
+    vsets = [parallel.alloc_result(B, eng.device)[1]]
+    runner = parallel.ShardedRunner(lambda f, v: eng.forward(f, out=v), eng.device) if use_dist else None
+    run_pipelined(args.warmup, frames, eng=eng, runner=runner, vsets=vsets)
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    last = run_pipelined(args.steps, frames, eng=eng, runner=runner, vsets=vsets)
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = True
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        # every rank holds every rank's rows, in frame order
+        for r in range(world):
+            want = parallel.alloc_result(B, eng.device)[1]
+            StandInEngine.fill(torch.from_numpy(synth.make_frames(B, seed=r, structured=False)), want)
+            ok = ok and all(torch.equal(last[k][r * B:(r + 1) * B], want[k]) for k in want)
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'STAND-IN plumbing run (no GPU, no model): not a measurement', 'value': round(world * B * args.steps / dt, 2),
+                          'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'stand-in engine on the CPU over gloo',
+                          'config': {'workload': 'stand-in', 'frames_per_gpu': B, 'global_batch': B * world,
+                                     'parallelism': 'frame-sharded x%d' % world,
+                                     'gather': 'gloo all-gather of result slots per batch' if use_dist else 'none (one rank)'},
+                          'gathered_rows_ok': ok}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit('stand-in run: gathered rows differ from what the ranks produced')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -536,17 +627,23 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default, 1 per context with --pipeline >= 2)')
     ap.add_argument('--pipeline', type=int, default=2, help='contexts taking batches in turn on their own streams (engine.EnginePool): the tail of one batch overlaps the head of the next; 1 = one context')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
+    ap.add_argument('--standin', action='store_true', help=argparse.SUPPRESS)     # CPU plumbing run over gloo (tests only)
     args = ap.parse_args()
 
     if args.pmc_child:
         pmc_child(args.batch, args.precision)
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around this process: become the launcher (one rank per GPU), rank 0 of the children prints the line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but the launcher started %d rank(s) (WORLD_SIZE): they must agree' % (args.gpus, world))
+    if args.standin:
+        standin_main(args, rank, world)
+        return
     torch.cuda.set_device(local_rank)
     dist = None
     # ACRMI_FORCE_DIST=1 exercises the RCCL path (init, all-gather, barriers) even at world size 1 (1-GPU boxes)

@@ -234,3 +234,39 @@ def test_shard_range_and_buffer_layout():
     assert v['slots'].shape == (3, 2, 176) and v['verts'].shape == (3, 2, 778, 3) and v['joints'].shape == (3, 2, 21, 3)
     v['joints'].fill_(7.0)
     assert flat[-1] == 7.0 and v['verts'].is_contiguous()
+
+
+def _run_bench(argv, env_drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=env, cwd=ROOT, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return p, (json.loads(lines[-1]) if lines and lines[-1].lstrip().startswith('{') else None)
+
+
+def test_bench_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it spawns its two ranks itself
+    (torch.distributed.run on 127.0.0.1), runs bench.py's N > 1 loop (ShardedRunner + run_pipelined + barriers + MAX over
+    ranks) - here with the CPU stand-in engine over gloo - and rank 0's JSON line is the LAST line of stdout, rc 0."""
+    p, line = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2', '--standin'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None, p.stdout[-2000:]
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['warmup'] == 1
+    assert line['config']['global_batch'] == 4 and line['gathered_rows_ok'] is True
+    assert 'STAND-IN' in line['metric']      # can never be mistaken for a measurement
+    # one rank, same entry point
+    p1, line1 = _run_bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '2', '--standin'])
+    assert p1.returncode == 0 and line1['n_gpus'] == 1
+
+
+def test_bench_refuses_a_launcher_of_the_wrong_size():
+    """--gpus N under a launcher that started M != N ranks is an error, not a silently different job."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--standin'], env=env, cwd=ROOT,
+                       timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and 'must agree' in p.stderr
