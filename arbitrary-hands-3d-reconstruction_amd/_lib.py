@@ -13,7 +13,7 @@ CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV / acrmi_conv2d's algo: ACRMI_C
 CONV_SPLITK = 16       # acrmi_op.flags of a CONV: ACRMI_CONV_SPLITK
 OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF, OPT_MANO_FP16 = 1, 2, 3, 4, 5, 6, 7
 OPT_LANE_PLAN = 8
-VERSION = 301
+VERSION = 302
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
@@ -49,7 +49,8 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_set_option', 'acrmi_point_heads', 'acrmi_set_option_f', 'acrmi_smooth', 'acrmi_smooth_reset',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias',
            'acrmi_buffer_dtype', 'acrmi_conv2d_h16', 'acrmi_conv2d_splitk', 'acrmi_conv2d_splitk_workspace',
-           'acrmi_decode_gated', 'acrmi_decode_maps_gated', 'acrmi_share_weights']
+           'acrmi_decode_gated', 'acrmi_decode_maps_gated', 'acrmi_share_weights', 'acrmi_mano_rotmat', 'acrmi_heads',
+           'acrmi_backbone_channels']
 
 _lib = None
 
@@ -92,6 +93,9 @@ def lib():
     L.acrmi_decode_maps_gated.argtypes = [f32p, f32p, i32, f32p, f32p, i32, f32p, f32p, i32, i32, C.c_float, vp, f32p, vp]
     L.acrmi_mano.argtypes = [vp, f32p, i32, f32p, i32, vp, i32, i32, f32p, f32p, f32p, f32p, i32, f32p, f32p, f32p,
                              f32p, vp]
+    L.acrmi_mano_rotmat.argtypes = [vp, f32p, f32p, i32, vp, i32, i32, f32p, f32p, f32p, vp]
+    L.acrmi_heads.argtypes = [vp, f32p, i32, vp]
+    L.acrmi_backbone_channels.argtypes = [vp]
     L.acrmi_forward.argtypes = [vp, u8p, i32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp]
     L.acrmi_conv2d.argtypes = [f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, i32, f32p, i32, i32, f32p, i32, i32,
                                i32, i32, i32, i32, i32, i32, vp]

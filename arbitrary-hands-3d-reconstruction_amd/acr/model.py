@@ -112,10 +112,15 @@ class ACR(object):
         return eng.buffer(eng.program['heads'].backbone_buf, B, backbone_channels(self._width)).permute(0, 3, 1, 2).float().contiguous()
 
     @torch.no_grad()
-    def head_forward(self, image):
-        """acr/model.py:47-65 (takes the frames, not backbone features: the network is one resident program)."""
-        eng = self.engine(image.shape[0])
-        B = eng.backbone_heads(image)
+    def head_forward(self, x):
+        """acr/model.py:47-65.  x: backbone features, float [B,32,128,128] as the reference takes them (e.g. what
+        `self.backbone(image)` returned: `model.head_forward(model.backbone(img))` works as on the reference) - the heads run
+        on them (acrmi_heads); or uint8 frames [B,512,512,3], the whole resident program in one go."""
+        eng = self.engine(x.shape[0])
+        if x.dtype == torch.uint8:
+            B = eng.backbone_heads(x)
+        else:
+            B = eng.heads(x)
         return eng.head_maps(B)
 
     @torch.no_grad()

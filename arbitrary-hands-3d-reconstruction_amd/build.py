@@ -26,15 +26,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, experiments=False):
+    """experiments: -DACRMI_EXPERIMENTS - the library then reads the environment switches of timing experiments / A-B runs
+    (csrc/kernels.h experiment_env: ACRMI_ABLATE_LANE_SYNC, ACRMI_EVENT_FLAGS, ACRMI_PLAN_WAIT_US, ACRMI_XCD_SWIZZLE,
+    ACRMI_CONV_DMA, ACRMI_WINO24B).  The production build ignores them."""
+    if not force and not experiments and not needs_build():
         return LIB
     hipcc = _hipcc()
+    flags = FLAGS + (['-DACRMI_EXPERIMENTS'] if experiments else [])
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -53,5 +57,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv, experiments='--experiments' in sys.argv)
     print(LIB)

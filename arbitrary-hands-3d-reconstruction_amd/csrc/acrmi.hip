@@ -17,7 +17,8 @@ int fail(acrmi_ctx* c, int code, const char* fmt, ...) {
 // the blob is freed by the last context that holds it (contexts are single-threaded per the ABI; sharing contexts of one
 // pool are driven by one host thread)
 void release_weights(acrmi_ctx* c) {
-  if (c->weights_ref && --*c->weights_ref == 0) {
+  // (the use count is atomic: contexts of one pool may be destroyed / re-programmed from different host threads)
+  if (c->weights_ref && c->weights_ref->fetch_sub(1) == 1) {
     (void)hipFree(c->weights);
     delete c->weights_ref;
   }
@@ -71,23 +72,31 @@ int acrmi_load_weights(acrmi_ctx* c, const float* blob, size_t n) {
   if (!c || !blob || n == 0) return fail(c, ACRMI_EINVAL, "acrmi_load_weights: bad arguments");
   ON_DEVICE(c);
   release_weights(c);
-  HIPCHK(c, hipMalloc(&c->weights, n * sizeof(float)));
-  HIPCHK(c, hipMemcpy(c->weights, blob, n * sizeof(float), hipMemcpyHostToDevice));
+  // the context takes the blob only once it is complete on the device: a failed copy leaves it without weights, not with a
+  // blob that has no use count
+  float* w = nullptr;
+  HIPCHK(c, hipMalloc(&w, n * sizeof(float)));
+  hipError_t e = hipMemcpy(w, blob, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(w);
+    return fail(c, ACRMI_EHIP, "acrmi_load_weights: hipMemcpy of %zu floats: %s", n, hipGetErrorString(e));
+  }
+  c->weights = w;
   c->n_weights = n;
-  c->weights_ref = new int(1);
+  c->weights_ref = new std::atomic<int>(1);
   return ACRMI_OK;
 }
 
 int acrmi_share_weights(acrmi_ctx* c, acrmi_ctx* donor) {
   if (!c || !donor || c == donor) return fail(c, ACRMI_EINVAL, "acrmi_share_weights: bad arguments");
-  if (!donor->weights) return fail(c, ACRMI_ESTATE, "acrmi_share_weights: the donor holds no weights");
+  if (!donor->weights || !donor->weights_ref) return fail(c, ACRMI_ESTATE, "acrmi_share_weights: the donor holds no weights");
   if (c->device != donor->device) return fail(c, ACRMI_EINVAL, "acrmi_share_weights: contexts on different devices (%d, %d)", c->device, donor->device);
   ON_DEVICE(c);
   release_weights(c);
   c->weights = donor->weights;
   c->n_weights = donor->n_weights;
   c->weights_ref = donor->weights_ref;
-  ++*c->weights_ref;
+  c->weights_ref->fetch_add(1);
   return ACRMI_OK;
 }
 
@@ -340,6 +349,57 @@ int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* b
   m.lbs_f16 = c->mano_f16;
   HIPCHK(c, launch_mano(m, (hipStream_t)stream));
   return ACRMI_OK;
+}
+
+int acrmi_mano_rotmat(acrmi_ctx* c, const float* rotmats, const float* betas, int beta_stride, const int32_t* side, int H,
+                      int center_idx, float* verts, float* joints, float* center, void* stream) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_mano_rotmat: ctx is NULL");
+  if (H == 0) return ACRMI_OK;
+  if (H < 0 || !rotmats || !betas || !verts || !joints || center_idx >= 21)
+    return fail(c, ACRMI_EINVAL, "acrmi_mano_rotmat: bad arguments");
+  if (!c->have_mano[0] && !c->have_mano[1]) return fail(c, ACRMI_ESTATE, "acrmi_mano_rotmat: MANO tables not loaded");
+  ON_DEVICE(c);
+  ManoArgs m{};
+  m.t[0] = c->have_mano[0] ? c->mano[0] : c->mano[1];
+  m.t[1] = c->have_mano[1] ? c->mano[1] : c->mano[0];
+  m.poses = rotmats; m.pose_stride = 144; m.pose_rotmat = 1; m.betas = betas; m.beta_stride = beta_stride;
+  m.side = side; m.H = H; m.center_idx = center_idx;
+  m.verts = verts; m.joints = joints; m.center = center;
+  m.off_div = 1;
+  m.lbs_f16 = c->mano_f16;
+  HIPCHK(c, launch_mano(m, (hipStream_t)stream));
+  return ACRMI_OK;
+}
+
+int acrmi_heads(acrmi_ctx* c, const float* feat_nchw, int B, void* stream) {
+  if (!c || !feat_nchw) return fail(c, ACRMI_EINVAL, "acrmi_heads: bad arguments");
+  if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_heads: no program");
+  if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
+  const int bb = c->heads.backbone_buf;
+  const acrmi_buffer_desc& d = c->bufs[bb];
+  if (d.dtype != ACRMI_DT_F32)
+    return fail(c, ACRMI_EINVAL, "acrmi_heads: the program stores its backbone output in 16 bits; features are taken by "
+                                 "fp32-storage programs (fp32, fp16x3, bf16x3)");
+  // the head ops = everything behind the last op that writes the backbone map (acr/model.py:47: head_forward starts there)
+  int first = -1, c0 = 0;
+  for (int i = 0; i < (int)c->ops.size(); ++i)
+    if (c->ops[i].kind != ACRMI_OP_COORDFILL && c->ops[i].out_buf == bb) {
+      first = i + 1;
+      c0 = c->ops[i].out_coff + c->ops[i].cout * (c->ops[i].kind == ACRMI_OP_CONV ? c->ops[i].groups : 1);
+    }
+  if (first < 0 || c0 <= 0 || c0 > d.cs) return fail(c, ACRMI_ESTATE, "acrmi_heads: the program has no backbone output op");
+  ON_DEVICE(c);
+  HIPCHK(c, launch_nchw_to_nhwc(feat_nchw, B, c0, d.h, d.w, c->buf_ptr[bb], d.cs, 0, (hipStream_t)stream));
+  return run_program(c, nullptr, B, stream, /*point=*/false, first);
+}
+
+int acrmi_backbone_channels(acrmi_ctx* c) {
+  if (!c || !c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_channels: no program");
+  const int bb = c->heads.backbone_buf;
+  int c0 = 0;
+  for (const acrmi_op& op : c->ops)
+    if (op.kind != ACRMI_OP_COORDFILL && op.out_buf == bb) c0 = op.out_coff + op.cout * (op.kind == ACRMI_OP_CONV ? op.groups : 1);
+  return c0;
 }
 
 // decode + MANO of acrmi_forward on one stream

@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -40,7 +41,7 @@ struct acrmi_ctx {
   std::string err;
   float* weights = nullptr;     // the packed blob on the device - owned, or another context's (acrmi_share_weights)
   size_t n_weights = 0;
-  int* weights_ref = nullptr;   // host-side use count of `weights` shared by the contexts that hold it (null: no blob)
+  std::atomic<int>* weights_ref = nullptr;   // host-side use count of `weights` shared by the contexts that hold it (null: no blob)
   std::vector<acrmi_buffer_desc> bufs;
   std::vector<float*> buf_ptr;
   std::vector<acrmi_op> ops;
@@ -120,4 +121,4 @@ void comm_destroy(acrmi_ctx* c);                       // acrmi_comm.hip
 int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStream_t s, int lane = 0);
 bool op_active(const acrmi_op& op, bool point);
 void build_schedule(acrmi_ctx* c, bool point, bool large);
-int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point);
+int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point, int first_op = 0);

@@ -245,7 +245,7 @@ void build_schedule(acrmi_ctx* c, bool point, bool large) {
   // stream starts ~4.5 us after its producer ends, through an event on another stream ~21 us after (WAIT_MS below is the
   // difference); every other lane waited for costs the consumer's queue one barrier packet (SYNC_MS).
   constexpr float SYNC_MS = 0.002f, EVENT_MS = 0.002f;   // (EVENT_MS: what a profiled time includes)
-  static const float WAIT_MS = getenv("ACRMI_PLAN_WAIT_US") ? 1e-3f * (float)atof(getenv("ACRMI_PLAN_WAIT_US")) : 0.016f;
+  static const float WAIT_MS = experiment_env("ACRMI_PLAN_WAIT_US") ? 1e-3f * (float)atof(experiment_env("ACRMI_PLAN_WAIT_US")) : 0.016f;
   std::vector<float> fin(planned ? n : 0, 0.f), lane_free(max_lanes, 0.f);
   for (int j : S.order) {
     int lane = -1;
@@ -548,7 +548,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
 // from it (so they start after everything queued before this call) and join it at the end.
 static unsigned lane_event_flags() {
   static const unsigned f = [] {
-    const char* e = getenv("ACRMI_EVENT_FLAGS");      // experiment switch: extra hipEventCreateWithFlags bits (hex)
+    const char* e = experiment_env("ACRMI_EVENT_FLAGS");      // experiment switch: extra hipEventCreateWithFlags bits (hex)
     if (e) fprintf(stderr, "[acrmi] WARNING: ACRMI_EVENT_FLAGS=%s - lane events created with non-default flags (experiment)\n", e);
     return hipEventDisableTiming | (e ? (unsigned)strtoul(e, nullptr, 16) : 0u);
   }();
@@ -571,7 +571,7 @@ static int run_program_lanes(acrmi_ctx* c, const uint8_t* img, int B, hipStream_
     // timing ablation (WRONG results: data races between lanes): 1 = no waits, 2 = no waits and no records.  Loud, so that a
     // leaked environment variable cannot silently corrupt a real run.
     static const int ablate = [] {
-      const char* e = getenv("ACRMI_ABLATE_LANE_SYNC");
+      const char* e = experiment_env("ACRMI_ABLATE_LANE_SYNC");
       const int v = e ? atoi(e) : 0;
       if (v) fprintf(stderr, "[acrmi] WARNING: ACRMI_ABLATE_LANE_SYNC=%d - cross-lane synchronisation is DISABLED, results are WRONG "
                              "(timing experiment only)\n", v);
@@ -592,18 +592,20 @@ static int run_program_lanes(acrmi_ctx* c, const uint8_t* img, int B, hipStream_
   return r;
 }
 
-int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point) {
-  if (!c || !img) return fail(c, ACRMI_EINVAL, "acrmi_backbone_heads: bad arguments");
+// first_op > 0 (acrmi_heads): only ops [first_op, n) run - in program order on the caller's stream (the lanes' events of the
+// skipped ops would be stale) - and `img` is not read
+int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point, int first_op) {
+  if (!c || (!img && first_op <= 0)) return fail(c, ACRMI_EINVAL, "acrmi_backbone_heads: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_heads: no program");
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
   ON_DEVICE(c);
   static const bool dbg_sync = getenv("ACRMI_DEBUG_SYNC") != nullptr;   // attribute a fault/hang to an op
-  if (c->sched[point ? 1 : 0][B > AUTO_SMALL_BATCH ? 1 : 0].n_lanes > 1 && !dbg_sync)
+  if (c->sched[point ? 1 : 0][B > AUTO_SMALL_BATCH ? 1 : 0].n_lanes > 1 && !dbg_sync && first_op <= 0)
     return run_program_lanes(c, img, B, (hipStream_t)stream, point);
   int i = 0;
   for (const acrmi_op& op : c->ops) {
     ++i;
-    if (!op_active(op, point)) continue;
+    if (!op_active(op, point) || i - 1 < first_op) continue;
     if (dbg_sync) fprintf(stderr, "[acrmi] op %d kind %d B %d\n", i - 1, (int)op.kind, B), fflush(stderr);
     int r = run_op(c, op, img, B, (hipStream_t)stream);
     if (r) return r;

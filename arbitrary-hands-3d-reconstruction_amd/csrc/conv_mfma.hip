@@ -540,7 +540,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   std::lock_guard<std::recursive_mutex> launch_lock(g_init_mutex);
   a.dbg = g_dbg;
   a.phase_delay = g_phase_delay;
-  static const char* swz_env = getenv("ACRMI_XCD_SWIZZLE");      // A/B runs: 0 = round-robin item order
+  static const char* swz_env = experiment_env("ACRMI_XCD_SWIZZLE");      // A/B runs: 0 = round-robin item order
   a.xcd_swizzle = swz_env ? atoi(swz_env) : g_xcd_swizzle;
   {   // halo / pad-channel lanes of the LDS-DMA loaders read zeros from here (one small allocation per device)
     static float* zeros[MAX_DEVICES] = {};

@@ -30,6 +30,34 @@ hipError_t launch_u8norm(const uint8_t* img, long n_pixels, float* out, hipStrea
   return hipGetLastError();
 }
 
+// fp32 NCHW -> a channel slice of an NHWC buffer.  A workgroup moves a [C <= 64][64 pixels] tile through LDS: reads are
+// coalesced along the pixels of a channel plane, writes along the channels of a pixel.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, long HW,
+                                                           float* __restrict__ out, int cs, int coff) {
+  __shared__ float tile[64][65];
+  const long tiles_per_frame = (HW + 63) / 64;
+  for (long t = blockIdx.x; t < (long)B * tiles_per_frame; t += gridDim.x) {
+    const int b = (int)(t / tiles_per_frame);
+    const long p0 = (t % tiles_per_frame) * 64;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int px = threadIdx.x & 63;
+      for (int c = threadIdx.x >> 6; c < 64; c += 4)
+        if (c0 + c < C && p0 + px < HW) tile[c][px] = in[((long)b * C + c0 + c) * HW + p0 + px];
+      __syncthreads();
+      const int ch = threadIdx.x & 63;
+      for (int q = threadIdx.x >> 6; q < 64; q += 4)
+        if (c0 + ch < C && p0 + q < HW) out[((long)b * HW + p0 + q) * cs + coff + c0 + ch] = tile[ch][q];
+      __syncthreads();
+    }
+  }
+}
+hipError_t launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, int cs, int coff, hipStream_t s) {
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)B * ((HW + 63) / 64) * 256, 256)), dim3(256), 0, s, in, B, C, HW, out,
+                     cs, coff);
+  return hipGetLastError();
+}
+
 // bilinear x2, align_corners=True (F.interpolate at acr/model.py:432): src = dst*(in-1)/(out-1)
 __global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict__ in, int B, int H, int W, int in_cs,
                                                          int in_coff, int C4, float* __restrict__ out, int out_cs,

@@ -4,7 +4,21 @@
 #include <stdint.h>
 #include <mutex>
 
+#include <stdlib.h>
+
 namespace acrmi {
+
+// Environment switches of timing experiments / A-B runs (lane-sync ablation, event flags, loader and kernel-frame A/B) exist
+// only in a library built with -DACRMI_EXPERIMENTS (`python -m <package>.build --experiments`); the production library does
+// not read them.  Diagnostics (ACRMI_DEBUG*) and configuration (ACRMI_RCCL_LIB) are plain getenv.
+inline const char* experiment_env(const char* name) {
+#ifdef ACRMI_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 struct ConvArgs {
   const float* in;
@@ -96,6 +110,9 @@ hipError_t launch_fuse_sum(const FuseArgs& a, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int pad_top, int pad_left, int out_size,
                              uint8_t* out, hipStream_t s);
 hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s);
+// fp32 NCHW [B,C,H,W] -> channels [coff, coff + C) of an NHWC buffer with channel stride cs (acrmi_heads: backbone features a
+// caller hands to head_forward, acr/model.py:47-53)
+hipError_t launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, float* out, int cs, int coff, hipStream_t s);
 hipError_t launch_coordfill(float* buf, int B, int H, int W, int cs, int coff, hipStream_t s);
 // 16-bit storage variants (dtype = ACRMI_DT_F16 / ACRMI_DT_BF16; strides and offsets in elements, C % 8 == 0)
 hipError_t launch_maxpool3s2(const float* in, int B, int H, int W, int in_cs, int in_coff, int C, float* out, int out_cs,
@@ -198,6 +215,8 @@ struct ManoArgs {
   const float* offsets; int off_div;   // offsets row = hand row / off_div
   float *verts_camed, *pj2d, *pj2d_org;
   int lbs_f16;                         // blend-shape tables and skinning weights from their f16 copies
+  int pose_rotmat;                     // 1: `poses` rows are 16 row-major 3x3 rotation matrices (joint_rot_mode='rotmat',
+                                       // mano/manolayer.py:151-162): no Rodrigues, no hands_mean
 };
 hipError_t launch_mano(const ManoArgs& a, hipStream_t s);
 hipError_t launch_cam_trans(const float* joints, const float* pj2d, int n, float focal, float img, float* out, hipStream_t s);

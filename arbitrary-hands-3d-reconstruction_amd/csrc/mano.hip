@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
 
   const float* pose = a.poses + (size_t)row * a.pose_stride;
   if (tid < 10) sBeta[tid] = a.betas[(size_t)row * a.beta_stride + tid];
-  if (tid < 16) {
+  if (a.pose_rotmat) {
+    // joint_rot_mode='rotmat' (mano/manolayer.py:151-162): the caller's 16 rotation matrices (already projected onto SO(3) by
+    // batch_rotprojs on the host, like the reference does on the CPU), root first; th_hands_mean plays no part
+    if (tid < 144) sR[tid / 9][tid % 9] = pose[tid];
+  } else if (tid < 16) {
     // batch_rodrigues (mano/manolayer.py:423-434) + quat2mat (:396-421)
     float ax = pose[3 * tid], ay = pose[3 * tid + 1], az = pose[3 * tid + 2];
     if (tid > 0) {

@@ -132,8 +132,10 @@ class Engine(object):
         pools, RCCL, another context) may share a queue with them: measured 7.5-9.9 ms per batch-1 call with four lanes
         in that state against 3.4 ms with their own queues and 5.0 ms on one stream.  Results do not depend on the
         assignment (same kernels, same order per buffer).  When the winner is what the library picks by itself for this
-        batch (4 lanes below 32 frames, 2 from 32 on) the lane option goes back to 0 = by batch size, so other batch
-        sizes keep their own default.  Returns ((lanes, planned), {(lanes, planned): ms})."""
+        batch (4 lanes up to 32 frames, 2 above) the lane option goes back to 0 = by batch size, so other batch
+        sizes keep their own default; a measurement taken at a batch of the OTHER class than the one the context was built
+        for (max_batch <= 32 / > 32) only sets the plan flag and leaves the lane count "by batch size".
+        Returns ((lanes, planned), {(lanes, planned): ms}) - `lanes` is what was measured fastest, `self.lanes` what is set."""
         import time
         if self.program is None:
             raise _lib.AcrmiError('no checkpoint loaded')
@@ -157,11 +159,14 @@ class Engine(object):
         best = min(ms, key=ms.get)
         self.set_lane_plan(best[1])
         # The measurement was taken at `batch`; it only overrides the library's choice for contexts that serve such batches
-        # (max_batch <= 32 = the library's small-batch schedule: 4 lanes up to 32 frames, 2 above).  A context built for
-        # large batches keeps "by batch size": a batch-1 winner of 1 or 6 lanes must not replace the 2 lanes of its
-        # 64-frame calls.
-        small_ctx = self.max_batch <= 32
-        self.set_lanes(best[0] if small_ctx and best[0] != (4 if batch <= 32 else 2) else 0)
+        # (the library's schedules: 4 lanes up to 32 frames, 2 above).  A context built for large batches keeps "by batch
+        # size" after a batch-1 measurement: a batch-1 winner of 1 or 6 lanes must not replace the 2 lanes of its 64-frame
+        # calls
+        # ... and the other way round: tune_lanes(batch=64) on a max_batch=64 context IS a measurement of the class that context
+        # serves, and is applied.  Classes as in the library: up to 32 frames / above (AUTO_SMALL_BATCH).
+        same_class = (batch > 32) == (self.max_batch > 32)
+        default = 4 if batch <= 32 else 2
+        self.set_lanes(best[0] if same_class and best[0] != default else 0)
         return best, ms
 
     def set_conf_thresh(self, thresh):
@@ -274,6 +279,22 @@ class Engine(object):
         _lib.check(self.L.acrmi_backbone_heads(self.ctx, _ptr(img), B, _stream(self.device)), self.ctx)
         return B
 
+    def heads(self, features):
+        """acr/model.py:47-65 on backbone features the caller holds: float [B, C0, 128, 128] (NCHW, what the reference's
+        head_forward takes; C0 = 32 for HRNet-W32) -> the heads run on them, results as after backbone_heads (head_maps /
+        decode).  fp32-storage programs (acrmi_heads)."""
+        if self.program is None:
+            raise _lib.AcrmiError('no checkpoint loaded')
+        c0 = self.L.acrmi_backbone_channels(self.ctx)
+        _lib.check(c0, self.ctx)
+        if features.dim() != 4 or tuple(features.shape[1:]) != (c0, 128, 128) or not features.is_floating_point():
+            raise ValueError('features must be float [B,%d,128,128] (NCHW), got %s %s' % (c0, features.dtype, tuple(features.shape)))
+        B = features.shape[0]
+        self.ensure_batch(B)
+        f = features.to(self.device, torch.float32).contiguous()
+        _lib.check(self.L.acrmi_heads(self.ctx, _ptr(f), B, _stream(self.device)), self.ctx)
+        return B
+
     def buffer(self, buf_id, B, channels=None):
         """Zero-copy torch view [B,h,w,cs] of a program buffer (NHWC) in its storage type (float32 / float16 /
         bfloat16: 16-bit programs keep the activations between layers in 16 bits)."""
@@ -316,11 +337,25 @@ class Engine(object):
             _lib.check(self.L.acrmi_decode_gated(self.ctx, B, _ptr(g), _ptr(slots), _stream(self.device)), self.ctx)
         return slots
 
-    def mano(self, poses, betas, side, center_idx=9, cam=None, offsets=None):
-        """poses [H,48], betas [H,10] float32 on device; side: int tensor [H] (0 left, 1 right)."""
+    def mano(self, poses, betas, side, center_idx=9, cam=None, offsets=None, rotmat=False):
+        """poses [H,48], betas [H,10] float32 on device; side: int tensor [H] (0 left, 1 right).
+        rotmat: poses are [H,16,3,3] orthonormal rotation matrices (acrmi_mano_rotmat; no projection outputs)."""
         H = poses.shape[0]
         dev = self.device
         poses = poses.to(dev, torch.float32).contiguous()
+        if rotmat:
+            if tuple(poses.shape[1:]) != (16, 3, 3) or cam is not None:
+                raise ValueError('rotmat poses are [H,16,3,3]; the projection is not part of this mode')
+            betas = betas.to(dev, torch.float32).contiguous()
+            verts = torch.empty(H, 778, 3, dtype=torch.float32, device=dev)
+            joints = torch.empty(H, 21, 3, dtype=torch.float32, device=dev)
+            center = torch.empty(H, 1, 3, dtype=torch.float32, device=dev)
+            if H:
+                side = side.to(dev, torch.int32).contiguous()
+                _lib.check(self.L.acrmi_mano_rotmat(self.ctx, _ptr(poses), _ptr(betas), 10, _ptr(side), H,
+                                                    -1 if center_idx is None else int(center_idx), _ptr(verts), _ptr(joints),
+                                                    _ptr(center), _stream(dev)), self.ctx)
+            return verts, joints, center, {}
         betas = betas.to(dev, torch.float32).contiguous()
         verts = torch.empty(H, 778, 3, dtype=torch.float32, device=dev)
         joints = torch.empty(H, 21, 3, dtype=torch.float32, device=dev)

@@ -69,6 +69,21 @@ def load_mano_pkl(path):
             'kintree_table': _arr(dd['kintree_table']).astype(np.int64)}
 
 
+def batch_rotprojs(rotmats):
+    """mano/manolayer.py:436-453: every 3x3 matrix of [N,J,3,3] -> the nearest rotation U V^T (CPU SVD, like the reference),
+    the last COLUMN negated when the result is a reflection."""
+    m = rotmats.detach().float().cpu()
+    out = torch.empty_like(m)
+    for b in range(m.shape[0]):
+        for r in range(m.shape[1]):
+            U, S, V = torch.svd(m[b, r])
+            rot = torch.matmul(U, V.transpose(0, 1))
+            if rot.det() < 0:
+                rot[:, 2] = -1 * rot[:, 2]
+            out[b, r] = rot
+    return out
+
+
 class ManoLayer(object):
     def __init__(self, center_idx=None, flat_hand_mean=True, ncomps=6, side='right', mano_root='model_data/mano/',
                  use_pca=True, root_rot_mode='axisang', joint_rot_mode='axisang', robust_rot=False, tables=None,
@@ -76,9 +91,8 @@ class ManoLayer(object):
         if root_rot_mode != 'axisang':
             # (the reference itself cannot run this mode: mano/manolayer.py:148-150 calls a module `rot6d` it never imports)
             raise ValueError("root_rot_mode=%r: only 'axisang' is implemented" % (root_rot_mode,))
-        if not use_pca and joint_rot_mode != 'axisang':
-            raise ValueError("joint_rot_mode=%r without use_pca (rotation-matrix poses through batch_rotprojs, "
-                             "mano/manolayer.py:152-163) is not implemented" % (joint_rot_mode,))
+        if not use_pca and joint_rot_mode not in ('axisang', 'rotmat'):
+            raise ValueError("joint_rot_mode=%r: 'axisang' or 'rotmat'" % (joint_rot_mode,))
         if side not in ('left', 'right'):
             raise ValueError('side must be "left" or "right"')
         if use_pca and not 0 < ncomps <= 45:
@@ -143,6 +157,14 @@ class ManoLayer(object):
             self.sync(self._engine)
         eng = self._engine
         N = th_pose_coeffs.shape[0]
+        rotmat = not self.use_pca and self.joint_rot_mode == 'rotmat'
+        if rotmat:
+            # mano/manolayer.py:151-162: [N,16,3,3] matrices, projected onto SO(3) one by one with a CPU SVD exactly as the
+            # reference's batch_rotprojs does (:436-453, U V^T with the last column flipped when det < 0); the kernel takes the
+            # rotations as they are (acrmi_mano_rotmat)
+            if th_pose_coeffs.dim() != 4 or tuple(th_pose_coeffs.shape[1:]) != (16, 3, 3):
+                raise ValueError('joint_rot_mode="rotmat": th_pose_coeffs must be [N,16,3,3], got %s' % (tuple(th_pose_coeffs.shape),))
+            th_pose_coeffs = batch_rotprojs(th_pose_coeffs.detach().float().cpu())
         if self.use_pca:      # PCA coordinates -> the 45 axis-angle values (the kernel adds th_hands_mean, :132-135)
             c = th_pose_coeffs.detach().float().cpu()
             th_pose_coeffs = torch.cat([c[:, :3], c[:, 3:3 + self.ncomps].mm(self.th_selected_comps)], 1)
@@ -155,7 +177,7 @@ class ManoLayer(object):
         if bool(root_palm):
             # mano/manolayer.py:249-251: the wrist joint is replaced by the palm = mean of vertices 95 and 22 BEFORE the
             # root alignment, so the kernel runs unaligned and the alignment (:258-266) happens here
-            verts, joints, _, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=None)
+            verts, joints, _, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=None, rotmat=rotmat)
             joints = joints.clone()
             joints[:, 0] = (verts[:, 95] + verts[:, 22]) / 2
             if use_trans:
@@ -166,7 +188,7 @@ class ManoLayer(object):
             center = joints[:, self.center_idx].unsqueeze(1).clone()
             return verts - center, joints - center, center
         cidx = None if use_trans else self.center_idx
-        verts, joints, center, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=cidx)
+        verts, joints, center, _ = eng.mano(th_pose_coeffs, th_betas.contiguous(), side, center_idx=cidx, rotmat=rotmat)
         if use_trans:
             t = th_trans.to(verts.device).float().unsqueeze(1)
             return verts + t, joints + t, t

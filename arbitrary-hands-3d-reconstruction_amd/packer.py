@@ -950,7 +950,15 @@ def _lower_heads(P, sd, b, x34, c0, dt, point_heads, precision, width, taps):
         t1 = P.conv('towers.block%d.conv1' % k, t0, c1, 3, 1, True)
         t2 = P.conv('towers.block%d.conv2' % k, t1, c2, 3, 1, True, res=t0)
         P.set_mode(_lib.MODE_DENSE, n0)
-        if point_heads:
+        if point_heads and P.split16:
+            # split-operand programs: conv_x3_kernel finds the op's ONE power-of-two weight scale behind the fragments of ALL its
+            # groups (a.w[groups * 9 * tap floats], pack_conv_x3) - a 2-group clone of the 8-group pack would read the "scale"
+            # from inside group 2's halves.  The two center towers get their own packs (and their own scale).
+            n1 = len(P.ops)
+            P.conv('towers.block%d.conv1.centers' % k, t0, c1[:2], 3, 1, True, out=t1)
+            P.conv('towers.block%d.conv2.centers' % k, t1, c2[:2], 3, 1, True, res=t0, out=t2)
+            P.set_mode(_lib.MODE_POINT, n1)
+        elif point_heads:
             for j in (n0, n0 + 1):
                 P.clone_op(j, P.op_info[j]['name'] + '.centers', 2.0 / len(towers), groups=2, mode=_lib.MODE_POINT)
         P.release(t1, t0)

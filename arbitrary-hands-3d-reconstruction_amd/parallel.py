@@ -122,12 +122,15 @@ class ShardedRunner(object):
         import ctypes as C
         from . import _lib
         raw = C.c_void_p()
-        _lib.check(_lib.lib().acrmi_stream_create(self.device.index or 0, C.byref(raw)))
+        # (an index-less 'cuda' device means the CURRENT device, not GPU 0)
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(_lib.lib().acrmi_stream_create(index, C.byref(raw)))
         self._raw_comm_stream = raw
         return torch.cuda.ExternalStream(raw.value, device=self.device)
 
     def close(self):
-        """Releases the library stream the gathers ran on (after every ticket has been collected)."""
+        """Releases the library stream the gathers ran on (after every ticket has been collected).  Also runs when the
+        runner is garbage-collected or leaves a `with` block: a runner never leaks its stream."""
         raw = getattr(self, '_raw_comm_stream', None)
         if raw is not None:
             torch.cuda.synchronize(self.device)
@@ -135,6 +138,19 @@ class ShardedRunner(object):
             self._comm_stream = None
             _lib.lib().acrmi_stream_destroy(raw)
             self._raw_comm_stream = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library / torch may already be gone
+            pass
 
     def _set(self, n_local, turn):
         world = dist.get_world_size(self.group)
@@ -195,7 +211,10 @@ class ShardedRunner(object):
         """Strong-scaling entry: every rank sees the global batch and takes its contiguous shard.  A batch that does not
         divide by the world size is padded per rank to ceil(n / world) frames (copies of the shard's last frame; a rank
         whose shard is empty runs copies of the batch's last frame) and the padding rows are dropped after the gather:
-        the result is exactly the n frames, in order."""
+        the result is exactly the n frames, in order.  The padding rows run through whatever `local_forward` does per batch:
+        with temporal smoothing switched on (Engine.set_temporal: ONE video stream per context, frames in order) a padded
+        shard would feed repeated frames into the One-Euro state - sharded batches are sets of independent frames, so
+        smoothing and sharding are not combined (acr/main.py smooths a single-frame stream)."""
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
         n = frames_global.shape[0]
         if n % world == 0:

@@ -129,7 +129,7 @@ def parity(eng, oracle):
             'against': 'oracle/ (CPU fp32 restatement pinned to the reference) on the cpu_baseline sample frames'}
 
 
-def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16', 'bf16', 'fp16x3', 'bf16x3')):
+def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, precisions=('fp16x3', 'bf16x3', 'fp16', 'bf16')):
     """Reported NEXT TO the headline, never as it: the reference's --model_precision fp16 branch (acr/model.py:33-37) and
     its bf16 twin as 16-bit programs (packer.lower) on the same frames, same K steps, two contexts in turn like the
     headline; `parity` = against the fp32 oracle (what 16-bit storage costs), not against a 16-bit reference (none
@@ -185,7 +185,12 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
                                         'single-stream time; at 16x the fp32 matrix rate the layers are HBM / L2 bound'}}
         if oracle is not None:
             r['parity'] = parity(eng, oracle)
-        res[prec] = r
+        if prec.endswith('x3'):
+            res[prec] = r
+        else:
+            # 16-bit STORAGE programs: not at the 1e-4 m bar (one rounding per layer of every activation) - an ablation of what
+            # the reference's autocast-style lowering costs on this network, never a result to use
+            res.setdefault('ablation_16bit_storage', {})[prec] = r
         pool.close()
     res['note'] = ('fp16 / bf16: activations between layers f16 / bf16 NHWC, BN-folded weights rounded once, fp32 '
                    'accumulate / bias / residual / ReLU, one rounding per layer; stem, head exits, attention pooling, '
@@ -306,19 +311,37 @@ def config3_video_stream(sd, tables, steps, warmup, local_rank, B=32, H=1080, W=
 
 def other_configs(tables, steps, warmup, local_rank):
     """The per-GPU workloads of the BASELINE.json configs the headline does not cover, each on its own synthetic checkpoint,
-    two contexts in turn like the headline: configs[1] (batch 32, ResNet-50, bf16) and configs[4] (batch 64 per GPU,
-    HRNet-W48, fp16 program, fp16 MANO LBS).  Neither network exists in the reference (its only backbone is HRNet-W32 and
+    two contexts in turn like the headline: configs[1] (batch 32, ResNet-50, "bf16") and configs[4] (batch 64 per GPU,
+    HRNet-W48, "fp16", fp16 MANO LBS).  Neither network exists in the reference (its only backbone is HRNet-W32 and
     `--backbone resnet50` is a dead flag, acr/config.py:95): both are build-defined (schema.py) and checked against the
-    build's own oracle (tests/test_gpu_h16.py), which `parity` here says instead of quoting a number."""
+    build's own oracle (tests/test_gpu_h16.py); `parity` quotes metres against the SAME checkpoint run as an fp32 program.
+    The REPORTED entry of each config is the program that does its arithmetic in the named 16-bit type AND stays at the
+    1e-4 m bar with no decision differing: the split-operand programs (fp32 tensors in HBM, bf16 / f16 operand halves on the
+    16-bit matrix pipe, csrc/conv_x3.inc).  The 16-bit STORAGE programs (activations rounded once per layer: 25 mm with 6 of 16
+    decisions differing for configs[1], 2.2 mm for configs[4]) are an `ablation`, not a result."""
     synth = pkg('synth')
-    res = {}
-    for name, width, prec, B, mano16 in (('configs[1] resnet50 bf16 batch32', 'resnet50', 'bf16', 32, False),
-                                          ('configs[1] resnet50 bf16x3 batch32 (bf16 ARITHMETIC on fp32 tensors: split operands, csrc/conv_x3.inc)',
-                                           'resnet50', 'bf16x3', 32, False),
-                                          ('configs[4] hrnet_w48 fp16 batch64 fp16-mano', 48, 'fp16', 64, True)):
-        sd = synth.make_state_dict(seed=0, width=width)
-        frames = torch.from_numpy(synth.make_frames(B, seed=0, structured=False)).cuda()
-        pool = pkg('engine').EnginePool(local_rank, n=2)
+    res = {'ablation_16bit_storage': {}}
+    for name, width, prec, B, mano16, primary in (
+            ('configs[1] resnet50 batch32: bf16x3 (bf16 ARITHMETIC on fp32 tensors: split operands, csrc/conv_x3.inc)', 'resnet50', 'bf16x3', 32, False, True),
+            ('configs[4] hrnet_w48 batch64 fp16-mano: fp16x3 (f16 ARITHMETIC on fp32 tensors: split operands, csrc/conv_x3.inc)', 48, 'fp16x3', 64, True, True),
+            ('configs[1] resnet50 bf16 STORAGE batch32', 'resnet50', 'bf16', 32, False, False),
+            ('configs[4] hrnet_w48 fp16 STORAGE batch64 fp16-mano', 48, 'fp16', 64, True, False)):
+        try:
+            r = _other_config(synth, tables, steps, warmup, local_rank, width, prec, B, mano16)
+        except Exception as exc:      # (one of the side configurations failing must not cost the headline line)
+            r = {'error': repr(exc)}
+        if primary:
+            res[name] = r
+        else:
+            res['ablation_16bit_storage'][name] = r
+    return res
+
+
+def _other_config(synth, tables, steps, warmup, local_rank, width, prec, B, mano16):
+    sd = synth.make_state_dict(seed=0, width=width)
+    frames = torch.from_numpy(synth.make_frames(B, seed=0, structured=False)).cuda()
+    pool = pkg('engine').EnginePool(local_rank, n=2)
+    try:
         pool.load_state_dict(sd, max_batch=B, lanes=1, precision=prec)
         pool.load_mano(tables)
         pool.configure(lambda e: e.set_mano_fp16(mano16))
@@ -339,32 +362,41 @@ def other_configs(tables, steps, warmup, local_rank):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         gflop = sum(i['flops'] for i in pool.engines[0].program['op_info'] if i.get('mode', 0) != pkg('_lib').MODE_POINT) / 1e9
-        # what the 16-bit program costs in metres: the same checkpoint as an fp32 program of this library on 8 structured
-        # frames (no reference network exists for these backbones, so the fp32 program - whose kernels and lowering are the
+        kernels = {}
+        for i in pool.engines[0].program['op_info']:
+            if i.get('kernel') and i.get('mode', 0) != pkg('_lib').MODE_POINT:
+                kernels[i['kernel']] = kernels.get(i['kernel'], 0) + 1
+        # what the program costs in metres: the same checkpoint as an fp32 program of this library on 8 structured frames (no
+        # reference network exists for these backbones, so the fp32 program - whose kernels and lowering are the
         # reference-pinned ones - is the yardstick; tests/test_gpu_h16.py checks both against the build's own oracle)
         L = pkg('_lib')
         pf = torch.from_numpy(synth.make_frames(8, seed=3)).cuda()
         o16 = pool.engines[0].forward(pf)
         torch.cuda.synchronize()
         o16 = {k: v.cpu().numpy() for k, v in o16.items()}
+    finally:
         pool.close()
-        e32 = pkg('engine').Engine(local_rank)
+    e32 = pkg('engine').Engine(local_rank)
+    try:
         e32.load_state_dict(sd, max_batch=8, precision='fp32')
         e32.load_mano(tables)
         o32 = {k: v.cpu().numpy() for k, v in e32.forward(pf).items()}
+    finally:
         e32.close()
-        f16, f32_ = o16['slots'][..., L.SLOT_FLAG] > 0.5, o32['slots'][..., L.SLOT_FLAG] > 0.5
-        same = (f16 == f32_) & (~f32_ | (o16['slots'][..., L.SLOT_FLATIND] == o32['slots'][..., L.SLOT_FLATIND]))
-        use = same & f32_
-        dv = np.linalg.norm(o16['verts'] - o32['verts'], axis=-1)[use]
-        res[name] = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
-                     'gflop_per_frame': round(gflop, 1), 'tflops': round(B * steps * gflop / dt / 1e3, 1),
-                     'gflop_per_frame_source': 'sum of the lowered program\'s algorithmic conv / pooling FLOPs (packer op_info), dense heads',
-                     'parity': {'max_vertex_l2_m': float(dv.max()) if dv.size else None, 'hands_compared': int(use.sum()),
-                                'decisions_differing': int((~same).sum()), 'frames': 8,
-                                'against': 'the SAME checkpoint as an fp32 program of this library (no reference network exists for '
-                                           'this backbone); per-op parity of both vs the build\'s own oracle: tests/test_gpu_h16.py'}}
-    return res
+    f16, f32_ = o16['slots'][..., L.SLOT_FLAG] > 0.5, o32['slots'][..., L.SLOT_FLAG] > 0.5
+    same = (f16 == f32_) & (~f32_ | (o16['slots'][..., L.SLOT_FLATIND] == o32['slots'][..., L.SLOT_FLATIND]))
+    use = same & f32_
+    dv = np.linalg.norm(o16['verts'] - o32['verts'], axis=-1)[use]
+    worst = float(dv.max()) if dv.size else None
+    return {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+            'precision': prec, 'mano_fp16_lbs': bool(mano16), 'conv_launches_by_kernel': kernels,
+            'gflop_per_frame': round(gflop, 1), 'tflops': round(B * steps * gflop / dt / 1e3, 1),
+            'gflop_per_frame_source': 'sum of the lowered program\'s algorithmic conv / pooling FLOPs (packer op_info), dense heads',
+            'parity': {'max_vertex_l2_m': worst, 'hands_compared': int(use.sum()),
+                       'decisions_differing': int((~same).sum()), 'frames': 8,
+                       'within_1e-4_m_and_no_decision_differing': bool(worst is not None and worst < 1e-4 and not (~same).any()),
+                       'against': 'the SAME checkpoint as an fp32 program of this library (no reference network exists for '
+                                  'this backbone); per-op parity of both vs the build\'s own oracle: tests/test_gpu_h16.py'}}
 
 
 def live_pmc(batch, timeout_s=300, precision='fp32'):
@@ -874,6 +906,8 @@ def main():
         line = json.dumps(out)
     else:
         line = None
+    if runner is not None:
+        runner.close()             # the library stream the gathers ran on
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

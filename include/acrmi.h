@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ACRMI_VERSION 301
+#define ACRMI_VERSION 302
 
 #define ACRMI_OK 0
 #define ACRMI_EINVAL (-1)  /* bad argument / unsupported shape  (reference: ValueError / assert) */
@@ -171,6 +171,13 @@ int acrmi_load_mano(acrmi_ctx* ctx, int side, const float* v_template, const flo
  * img_dev: uint8 [B,512,512,3] RGB NHWC (meta_data['image']).  Results stay in the
  * program's head buffers (see acrmi_buffer_ptr). */
 int acrmi_backbone_heads(acrmi_ctx* ctx, const uint8_t* img_dev, int B, void* stream);
+/* acr/model.py:47-65 (ACR.head_forward(x)): the heads alone on backbone features the caller holds - feat_nchw_dev is fp32
+ * [B, C0, 128, 128] (C0 = acrmi_backbone_channels: 32 for HRNet-W32), e.g. what acr.model.ACR.backbone returned.  The
+ * features are copied into the program's backbone map (coordinate channels are already there) and the ops behind the backbone
+ * run in program order on `stream`; results as after acrmi_backbone_heads (acrmi_buffer_ptr / acrmi_decode).  fp32-storage
+ * programs only (ACRMI_EINVAL for the 16-bit storage programs). */
+int acrmi_heads(acrmi_ctx* ctx, const float* feat_nchw_dev, int B, void* stream);
+int acrmi_backbone_channels(acrmi_ctx* ctx); /* channels of the backbone output (without the 2 coordinate maps); < 0: error */
 
 /* Device pointer / geometry of program buffer `buf` (valid until the next set_program); cs counts elements of
  * acrmi_buffer_dtype(ctx, buf) (ACRMI_DT_*, -1 for an unknown buffer). */
@@ -209,6 +216,13 @@ int acrmi_mano(acrmi_ctx* ctx, const float* poses, int pose_stride, const float*
                const int32_t* side, int H, int center_idx, float* verts, float* joints, float* center,
                const float* cam, int cam_stride, const float* offsets, float* verts_camed, float* pj2d,
                float* pj2d_org, void* stream);
+
+/* mano/manolayer.py:151-162 (joint_rot_mode='rotmat', use_pca=False): the pose of row r is rotmats[r*144..+144] = 16 row-major
+ * 3x3 rotation matrices, root first, ALREADY orthonormal (the reference projects them with a CPU SVD in batch_rotprojs,
+ * :436-453; the Python ManoLayer of this package does the same on the host).  No Rodrigues, th_hands_mean is not applied.
+ * Everything behind the rotations - blend shapes, joint regression, chain, skinning, tips, root alignment - is acrmi_mano's. */
+int acrmi_mano_rotmat(acrmi_ctx* ctx, const float* rotmats, const float* betas, int beta_stride, const int32_t* side,
+                      int H, int center_idx, float* verts, float* joints, float* center, void* stream);
 
 /* acr/utils.py:430-472 + :474-519 (estimate_translation_np / estimate_translation, the reference's closed-form
  * least-squares branch, unit joint confidences): joints [n,21,3] and pj2d [n,21,2] (in [-1,1]; the 2-D targets are

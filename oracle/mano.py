@@ -29,18 +29,37 @@ def batch_rodrigues(aa):
                         2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], 1)
 
 
+def batch_rotprojs(rotmats):
+    """mano/manolayer.py:436-453: [N,J,3,3] -> U V^T of each matrix's (CPU) SVD, last column negated for reflections."""
+    m = torch.as_tensor(rotmats, dtype=torch.float32)
+    out = torch.empty_like(m)
+    for b in range(m.shape[0]):
+        for r in range(m.shape[1]):
+            U, S, V = m[b, r].svd()
+            rot = torch.matmul(U, V.transpose(0, 1))
+            if rot.det() < 0:
+                rot[:, 2] = -1 * rot[:, 2]
+            out[b, r] = rot
+    return out
+
+
 @torch.no_grad()
 def mano_forward(tables, side, poses, betas, center_idx=9):
     """mano/manolayer.py:104-276.  tables: float32 arrays of one side (left: shapedirs already
     x-flipped by the caller, acr/mano_wrapper.py:35).  poses [N,48], betas [N,10]
-    -> verts [N,778,3], joints [N,21,3], center [N,1,3] (numpy float32)."""
+    -> verts [N,778,3], joints [N,21,3], center [N,1,3] (numpy float32).
+    poses [N,16,3,3]: joint_rot_mode='rotmat' (:151-162) - matrices through batch_rotprojs, no th_hands_mean.
+    center_idx None: no root alignment (center = None)."""
     T = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in tables.items()
          if k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'hands_mean')}
     poses = torch.as_tensor(poses, dtype=torch.float32)
     betas = torch.as_tensor(betas, dtype=torch.float32)
     N = poses.shape[0]
-    full = torch.cat([poses[:, :3], T['hands_mean'].view(1, 45) + poses[:, 3:48]], 1)
-    rot = batch_rodrigues(full.reshape(-1, 3)).view(N, 16, 9)
+    if poses.dim() == 4:
+        rot = batch_rotprojs(poses).reshape(N, 16, 9)
+    else:
+        full = torch.cat([poses[:, :3], T['hands_mean'].view(1, 45) + poses[:, 3:48]], 1)
+        rot = batch_rodrigues(full.reshape(-1, 3)).view(N, 16, 9)
     eye = torch.eye(3).view(1, 1, 9)
     pose_map = (rot[:, 1:] - eye).reshape(N, 135)
     R = rot.view(N, 16, 3, 3)
@@ -65,6 +84,8 @@ def mano_forward(tables, side, poses, betas, center_idx=9):
     rest = torch.cat([v_posed.transpose(2, 1), torch.ones(N, 1, 778)], 1)
     verts = (Tv * rest.unsqueeze(1)).sum(2).transpose(2, 1)[:, :, :3]
     jtr = torch.cat([G[:, :, :3, 3], verts[:, TIPS[side]]], 1)[:, JOINT_REORDER]
+    if center_idx is None:
+        return verts.numpy(), jtr.numpy(), None
     center = jtr[:, center_idx].unsqueeze(1)
     return (verts - center).numpy(), (jtr - center).numpy(), center.numpy()
 

@@ -78,6 +78,34 @@ def mano_option_inputs(name):
     return poses, betas, trans
 
 
+# joint_rot_mode='rotmat' (mano/manolayer.py:151-162, VERDICT r4 item 8): name -> (ctor kwargs, n, seed, noise)
+MANO_ROTMAT_CASES = {
+    'rotmat_right_c9': (dict(use_pca=False, joint_rot_mode='rotmat', side='right', center_idx=9), 3, 41, 0.0),
+    'rotmat_left_nocenter_noisy': (dict(use_pca=False, joint_rot_mode='rotmat', side='left', center_idx=None), 3, 42, 0.05),
+    'rotmat_right_c0_reflection': (dict(use_pca=False, joint_rot_mode='rotmat', side='right', center_idx=0), 2, 43, 0.02),
+}
+
+
+def mano_rotmat_inputs(name):
+    """[n,16,3,3] float32 matrices + betas: exact rotations (fp64 Rodrigues of seeded axis-angles), plus seeded noise so that
+    batch_rotprojs' SVD projection matters, plus - in the '_reflection' case - one matrix with a negated column (det < 0:
+    the reference's reflection branch)."""
+    kw, n, seed, noise = MANO_ROTMAT_CASES[name]
+    g = rng(1700 + seed)
+    aa = g.normal(0, 0.6, (n, 16, 3))
+    th = np.linalg.norm(aa, axis=-1, keepdims=True)
+    k = aa / th
+    K = np.zeros((n, 16, 3, 3))
+    K[..., 0, 1], K[..., 0, 2], K[..., 1, 0] = -k[..., 2], k[..., 1], k[..., 2]
+    K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -k[..., 0], -k[..., 1], k[..., 0]
+    R = np.eye(3) + np.sin(th)[..., None] * K + (1 - np.cos(th))[..., None] * (K @ K)
+    R = R + noise * g.normal(0, 1, R.shape)
+    if name.endswith('_reflection'):
+        R[0, 5, :, 1] *= -1
+    betas = g.normal(0, 1.0, (n, 10)).astype(np.float32)
+    return R.astype(np.float32), betas
+
+
 def decode_batch_maps(name):
     """Head-map dict (float32, NCHW, B = len(members)) of a decode batch: the members' maps, concatenated."""
     ms = [decode_maps(m) for m in DECODE_BATCHES[name]]

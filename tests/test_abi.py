@@ -25,8 +25,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'libacrmi.so does not export %s' % name
     assert sorted(L.EXPORTS) == declared
-    assert lib.acrmi_version() == L.VERSION == 301
-    for name in ('acrmi_allgather', 'acrmi_comm_init', 'acrmi_smooth', 'acrmi_set_option_f'):      # SURVEY.md 8b list
+    assert lib.acrmi_version() == L.VERSION == 302
+    for name in ('acrmi_allgather', 'acrmi_comm_init', 'acrmi_smooth', 'acrmi_set_option_f', 'acrmi_heads', 'acrmi_mano_rotmat'):      # SURVEY.md 8b list
         assert name in declared
 
 

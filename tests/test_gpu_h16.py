@@ -328,19 +328,25 @@ def test_16bit_vertex_error_against_the_reference_frames(precision, mano_tables)
     assert rep['max_vertex_err_m'] < (1e-2 if precision == 'fp16' else 1e-1), rep
 
 
-@pytest.mark.parametrize('width', [48, 'resnet50'])
-def test_hrnet_w48_fp32_matches_the_oracle(width, mano_tables):
+@pytest.mark.parametrize('width,precision,max_batch', [(48, 'fp32', 2), ('resnet50', 'fp32', 2), (48, 'fp32', 16), (48, 'fp16x3', 16),
+                                                       ('resnet50', 'bf16x3', 16)])
+def test_hrnet_w48_fp32_matches_the_oracle(width, precision, max_batch, mano_tables):
     """BASELINE.json configs[4]'s backbone (HRNet-W48: 48/96/192/384, heads on 48 + 2 channels) in fp32 against
     oracle/acr_net.py, which is state-dict driven and needs no change for the wider network - NO REFERENCE ORACLE (the
     reference hard-wires W32, acr/model.py:797-819); the W32 reading of the same code is pinned to the reference.
     'resnet50': configs[1]'s backbone (build-defined: torchvision's ResNet-50 trunk + three bilinear x2 / conv3x3 stages,
-    heads on 64 + 2 channels) against oracle/acr_net.resnet50_backbone - equally without a reference oracle."""
+    heads on 64 + 2 channels) against oracle/acr_net.resnet50_backbone - equally without a reference oracle.
+    max_batch 16: the LARGE-batch lowering (four-wave F(2x4,3x3), polyphase stride 2, streaming 1x1) of the wider networks;
+    'fp16x3' / 'bf16x3': the split-operand programs bench.py reports for configs[4] / configs[1] (other_configs) - under the
+    SAME tolerances as fp32 (head maps 1e-4 relative, vertices 1e-4 m against the fp32 oracle)."""
     synth = pkg('synth')
     sd = synth.make_state_dict(seed=0, width=width)
     x = torch.from_numpy(synth.make_frames(2, seed=0))
     eng = pkg('engine').Engine(0)
-    eng.load_state_dict(sd, max_batch=2)
+    eng.load_state_dict(sd, max_batch=max_batch, precision=precision)
     assert eng.program['width'] == width
+    if precision != 'fp32':
+        assert sum(i.get('kernel') in ('conv_x3_kernel', 'conv_x3p_kernel') for i in eng.program['op_info']) >= 60
     eng.load_mano(_flip_left(mano_tables))
     out = eng.forward(x.cuda())
     torch.cuda.synchronize()
@@ -359,7 +365,7 @@ def test_hrnet_w48_fp32_matches_the_oracle(width, mano_tables):
                 v, j, _ = omano.mano_forward(t[name], name, slots['poses'][b, h:h + 1], slots['betas'][b, h:h + 1])
                 assert np.abs(out['verts'][b, h].cpu().numpy() - v[0]).max() < 1e-4
                 n += 1
-    _report('%s_fp32_hands' % ('w48' if width == 48 else width), n)
+    _report('%s_%s_b%d_hands' % ('w48' if width == 48 else width, precision, max_batch), n)
     assert n >= 2
     eng.close()
 

@@ -76,6 +76,19 @@ def test_split_operand_program_matches_oracle_and_reference_golden(synth_sd, man
         np.testing.assert_array_equal(slots[b, :, L.SLOT_FLAG] > 0.5, ge['f%d_detection_flag' % b].astype(bool))
         assert np.abs(out['verts'][b].cpu().numpy() - ge['f%d_verts' % b]).max() < 1e-4
         assert np.abs(out['joints'][b].cpu().numpy() - ge['f%d_j3d' % b]).max() < 1e-4
+    # the point-heads variant of a split-operand program (what acr.main.ACR.forward_batch runs by default) -
+    # its center-tower convs carry their own packs and weight scale; same decisions, same meshes as the dense variant
+    assert eng.has_point_heads
+    dense = {k: v.clone() for k, v in out.items()}
+    eng.set_point_heads(True)
+    try:
+        pt = {k: v.clone() for k, v in eng.forward(torch.from_numpy(frames2).cuda()).items()}
+        torch.cuda.synchronize()
+    finally:
+        eng.set_point_heads(False)
+    _assert_point_matches_dense(pt, dense)
+    for b in range(2):
+        assert np.abs(pt['verts'][b].cpu().numpy() - ge['f%d_verts' % b]).max() < 1e-4
     eng.close()
 
 

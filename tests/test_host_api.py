@@ -336,3 +336,27 @@ def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
     assert n6 >= 190
     with pytest.raises(ValueError):
         packer.lower(synth_sd, precision='fp8')
+
+
+@pytest.mark.parametrize('precision', ['fp16x3', 'bf16x3'])
+def test_x3_weight_scale_sits_where_the_kernel_reads_it_for_every_op(synth_sd, precision):
+    """conv_x3_kernel / conv_x3p_kernel read the op's power-of-two weight scale at
+    a.w[groups * taps * ksteps * n_tiles * 512] - behind the fragments of ALL groups of the op AS LAUNCHED.  The point-heads
+    variant used to launch 2-group clones of the 8-group tower packs and read garbage (4e+20) there.  Every algo-6/7 op of the
+    program with point heads ON (the default of acr/main.py forward_batch) must find 2^-S of ITS OWN filters at that place."""
+    packer, L = pkg('packer'), pkg('_lib')
+    prog = packer.lower(synth_sd, precision=precision, point_heads=True, keep_weights=True)
+    blob = prog['blob']
+    seen, point = 0, 0
+    for op, info in zip(prog['ops'], prog['op_info']):
+        if op.kind != L.OP_CONV or (op.flags & 7) not in (6, 7):
+            continue
+        ksteps, n_tiles = op.cin // 16, (1 if op.cout <= 32 else (op.cout + 63) // 64 * 2)
+        pos = op.w_off + op.groups * op.ksize * op.ksize * ksteps * n_tiles * 512
+        ws = [w for (w, _) in info['wb']][:op.groups]
+        assert len(ws) == op.groups, info['name']
+        want = np.float32(2.0 ** -packer.x3_weight_shift(ws))
+        assert blob[pos] == want, (info['name'], float(blob[pos]), float(want))
+        seen += 1
+        point += op.mode == L.MODE_POINT
+    assert seen >= 190 and point == 4      # the four center-tower convs of the point-heads variant carry their own packs

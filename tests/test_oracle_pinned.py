@@ -122,6 +122,23 @@ def test_mano_matches_reference(mano_tables, n, seed, side):
     _close(c, g[key + '_center'], 1e-5, 2e-7)
 
 
+@pytest.mark.parametrize('name', list(cases.MANO_ROTMAT_CASES))
+def test_mano_rotmat_mode_matches_reference(name, mano_tables):
+    """joint_rot_mode='rotmat' (mano/manolayer.py:151-162, batch_rotprojs :436-453): the oracle against the REAL reference's
+    ManoLayer on seeded rotation matrices - exact, noisy (the SVD projection matters) and one reflection (det < 0)
+    (tests/golden/mano_rotmat.npz, make_golden_rotmat.py)."""
+    g = golden('mano_rotmat.npz')
+    kw, n, seed, noise = cases.MANO_ROTMAT_CASES[name]
+    rot, betas = cases.mano_rotmat_inputs(name)
+    v, j, c = omano.mano_forward(mano_tables[kw['side']], kw['side'], rot, betas, center_idx=kw['center_idx'])
+    _close(v, g[name + '_verts'], 1e-5, 5e-7)
+    _close(j, g[name + '_joints'], 1e-5, 5e-7)
+    if g[name + '_center'].size:
+        _close(c, g[name + '_center'], 1e-5, 5e-7)
+    else:
+        assert c is None
+
+
 def test_projection_matches_reference(mano_tables):
     g = golden('mano_cases.npz')
     poses, betas = cases.mano_inputs(4, 9)
