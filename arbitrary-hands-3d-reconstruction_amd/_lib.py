@@ -17,7 +17,7 @@ VERSION = 302
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
-E_INVAL, E_HIP, E_STATE, E_NOMEM = -1, -2, -3, -4
+E_INVAL, E_HIP, E_STATE, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5
 
 
 class BufferDesc(C.Structure):
@@ -50,13 +50,18 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias',
            'acrmi_buffer_dtype', 'acrmi_conv2d_h16', 'acrmi_conv2d_splitk', 'acrmi_conv2d_splitk_workspace',
            'acrmi_decode_gated', 'acrmi_decode_maps_gated', 'acrmi_share_weights', 'acrmi_mano_rotmat', 'acrmi_heads',
-           'acrmi_backbone_channels']
+           'acrmi_backbone_channels', 'acrmi_check_range']
 
 _lib = None
 
 
 class AcrmiError(RuntimeError):
     pass
+
+
+class AcrmiRangeError(AcrmiError, OverflowError):
+    """ACRMI_ERANGE: an 'fp16x3' program met an activation outside the f16 range (acrmi_check_range); the results since the
+    last check are invalid (and were written as NaN)."""
 
 
 def lib():
@@ -96,6 +101,7 @@ def lib():
     L.acrmi_mano_rotmat.argtypes = [vp, f32p, f32p, i32, vp, i32, i32, f32p, f32p, f32p, vp]
     L.acrmi_heads.argtypes = [vp, f32p, i32, vp]
     L.acrmi_backbone_channels.argtypes = [vp]
+    L.acrmi_check_range.argtypes = [vp, vp]
     L.acrmi_forward.argtypes = [vp, u8p, i32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp]
     L.acrmi_conv2d.argtypes = [f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, i32, f32p, i32, i32, f32p, i32, i32,
                                i32, i32, i32, i32, i32, i32, vp]
@@ -147,4 +153,6 @@ def check(rc, ctx=None):
     msg = msg.decode() if msg else 'acrmi error %d' % rc
     if rc == E_INVAL:
         raise ValueError(msg)
+    if rc == E_RANGE:
+        raise AcrmiRangeError(msg)
     raise AcrmiError(msg)

@@ -114,6 +114,7 @@ class ACR(object):
         finally:
             eng.set_point_heads(False)
             eng.set_temporal(False)
+        eng.check_range()      # 'fp16x3' only: an activation outside the f16 range is an error, not an empty result
         # cam_trans for every slot (acr/utils.py:399-412): the device least-squares kernel on [B*2] hands
         from .. import ops
         out['cam_trans'] = ops.cam_trans(out['joints'].view(-1, 21, 3), out['pj2d'].view(-1, 21, 2),

@@ -135,6 +135,7 @@ class ACR(object):
         B = eng.backbone_heads(img.contiguous())
         outputs = eng.head_maps(B) if cfg.get('return_maps', True) else {}
         outputs['slots'] = eng.decode(B)
+        eng.check_range()      # 'fp16x3' only: an activation outside the f16 range is an error, not a NaN / empty result
         if self._result_parser.batch_semantics == 'reference' and B > 1:
             # the reference's batch-wide prior rules (acr/result_parser.py:42-47,131): decided on the host from the first
             # decode's flags / centers, applied by a second decode (result_parser.reference_prior_gate)

@@ -319,12 +319,26 @@ int acrmi_decode_gated(acrmi_ctx* c, int B, const int32_t* prior_gate, float* sl
   if (B <= 0 || B > c->max_batch) return fail(c, ACRMI_EINVAL, "batch %d outside 1..%d", B, c->max_batch);
   ON_DEVICE(c);
   const acrmi_head_layout& h = c->heads;
-  int r = acrmi_decode_maps_gated(c->buf_ptr[h.center_buf[0]], c->buf_ptr[h.center_buf[1]], c->bufs[h.center_buf[0]].cs,
-                                  c->buf_ptr[h.params_buf[0]], c->buf_ptr[h.params_buf[1]], c->bufs[h.params_buf[0]].cs,
-                                  c->buf_ptr[h.prior_buf[0]], c->buf_ptr[h.prior_buf[1]], c->bufs[h.prior_buf[0]].cs, B,
-                                  c->conf_thresh, prior_gate, slots, stream);
+  int r = decode_maps_impl(c->buf_ptr[h.center_buf[0]], c->buf_ptr[h.center_buf[1]], c->bufs[h.center_buf[0]].cs,
+                           c->buf_ptr[h.params_buf[0]], c->buf_ptr[h.params_buf[1]], c->bufs[h.params_buf[0]].cs,
+                           c->buf_ptr[h.prior_buf[0]], c->buf_ptr[h.prior_buf[1]], c->bufs[h.prior_buf[0]].cs, B,
+                           c->conf_thresh, prior_gate, c->range_flag, slots, stream);
   if (r) c->err = g_err;
   return r;
+}
+
+int acrmi_check_range(acrmi_ctx* c, void* stream) {
+  if (!c) return fail(c, ACRMI_EINVAL, "acrmi_check_range: ctx is NULL");
+  if (!c->range_flag) return ACRMI_OK;      // no split-f16 convolution in the program: nothing can overflow
+  ON_DEVICE(c);
+  unsigned v = 0;
+  HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(c, hipMemcpy(&v, c->range_flag, sizeof(v), hipMemcpyDeviceToHost));
+  if (!v) return ACRMI_OK;
+  HIPCHK(c, hipMemset(c->range_flag, 0, sizeof(v)));
+  return fail(c, ACRMI_ERANGE, "an activation of the 'fp16x3' program left the f16 range (|x| > 65504): its split halves are "
+                               "inf / -inf and the results since the last check are invalid (slots and meshes were written as "
+                               "NaN); use precision 'bf16x3' or 'fp32' for this checkpoint");
 }
 
 int acrmi_mano(acrmi_ctx* c, const float* poses, int pose_stride, const float* betas, int beta_stride,

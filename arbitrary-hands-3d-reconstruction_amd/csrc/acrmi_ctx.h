@@ -51,6 +51,8 @@ struct acrmi_ctx {
   float* att_ws = nullptr;      // attention-pool workspace
   size_t att_ws_floats = 0;
   int* picks = nullptr;         // point heads: decoded centers per frame [max_batch,4]
+  unsigned* range_flag = nullptr;   // 'fp16x3' programs (algo 6): set by conv_x3 / conv_x3p when an activation left the f16 range
+                                    // (acrmi_check_range reads and clears it; acrmi_decode poisons the slots while it is set)
   bool point_heads = false;     // ACRMI_OPT_POINT_HEADS
   Schedule sched[2][2];         // [point][0: small batches / 1: large batches]
   // ACRMI_OPT_LANES: independent chains of the program on parallel HIP streams (lane 0 = the caller's stream)
@@ -122,3 +124,6 @@ int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStrea
 bool op_active(const acrmi_op& op, bool point);
 void build_schedule(acrmi_ctx* c, bool point, bool large);
 int run_program(acrmi_ctx* c, const uint8_t* img, int B, void* stream, bool point, int first_op = 0);
+int decode_maps_impl(const float* l_center, const float* r_center, int center_cs, const float* l_params, const float* r_params,
+                     int params_cs, const float* l_prior, const float* r_prior, int prior_cs, int B, float conf_thresh,
+                     const int32_t* prior_gate, const unsigned* poison, float* slots, void* stream);      // acrmi_ops.hip

@@ -1,11 +1,10 @@
 // libacrmi.so: the stand-alone operators of the C ABI (unit tests / callers with their own tensors; no context).
 #include "acrmi_ctx.h"
 
-extern "C" {
-
-int acrmi_decode_maps_gated(const float* l_center, const float* r_center, int center_cs, const float* l_params,
-                            const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
-                            int B, float conf_thresh, const int32_t* prior_gate, float* slots, void* stream) {
+// (poison: acrmi_decode_gated's range flag of an 'fp16x3' program; null for the stand-alone operator)
+int decode_maps_impl(const float* l_center, const float* r_center, int center_cs, const float* l_params,
+                     const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
+                     int B, float conf_thresh, const int32_t* prior_gate, const unsigned* poison, float* slots, void* stream) {
   if (!l_center || !r_center || !l_params || !r_params || !l_prior || !r_prior || !slots || B <= 0 || params_cs < 109 ||
       prior_cs < 106 || center_cs < 1 || !(conf_thresh == conf_thresh))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_decode_maps: bad arguments");
@@ -15,9 +14,19 @@ int acrmi_decode_maps_gated(const float* l_center, const float* r_center, int ce
   d.prior[0] = l_prior; d.prior[1] = r_prior; d.prior_cs = prior_cs;
   d.B = B; d.slots = slots; d.thresh = conf_thresh;
   d.prior_gate = prior_gate;
+  d.poison = poison;
   hipError_t e = launch_decode(d, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "decode launch: %s", hipGetErrorString(e));
   return ACRMI_OK;
+}
+
+extern "C" {
+
+int acrmi_decode_maps_gated(const float* l_center, const float* r_center, int center_cs, const float* l_params,
+                            const float* r_params, int params_cs, const float* l_prior, const float* r_prior, int prior_cs,
+                            int B, float conf_thresh, const int32_t* prior_gate, float* slots, void* stream) {
+  return decode_maps_impl(l_center, r_center, center_cs, l_params, r_params, params_cs, l_prior, r_prior, prior_cs, B, conf_thresh,
+                          prior_gate, nullptr, slots, stream);
 }
 
 int acrmi_decode_maps(const float* l_center, const float* r_center, int center_cs, const float* l_params,

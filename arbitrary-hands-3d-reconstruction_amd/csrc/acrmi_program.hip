@@ -20,6 +20,8 @@ void free_program(acrmi_ctx* c) {
   c->att_ws = nullptr;
   if (c->picks) (void)hipFree(c->picks);
   c->picks = nullptr;
+  if (c->range_flag) (void)hipFree(c->range_flag);
+  c->range_flag = nullptr;
   c->have_program = false;
 }
 
@@ -81,6 +83,7 @@ int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStrea
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
       a.algo = op.flags & 7;
+      a.range_flag = a.algo == 6 ? c->range_flag : nullptr;      // f16 operand halves: |x| must stay inside the f16 range
       a.dtype = di.dtype;                                    // 16-bit input: conv_h16.hip
       a.out_f32 = di.dtype != ACRMI_DT_F32 && dout.dtype == ACRMI_DT_F32;
       HIPCHK(c, launch_conv(a, s));
@@ -528,6 +531,11 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
   HIPCHK(c, hipMalloc(&c->picks, (size_t)max_batch * 4 * sizeof(int)));
+  for (int i = 0; i < n_ops; ++i)
+    if (ops[i].kind == ACRMI_OP_CONV && (ops[i].flags & 7) == 6 && !c->range_flag) {
+      HIPCHK(c, hipMalloc(&c->range_flag, sizeof(unsigned)));
+      HIPCHK(c, hipMemset(c->range_flag, 0, sizeof(unsigned)));
+    }
   c->op_ms[0].clear(); c->op_ms[1].clear();      // measured times belong to the previous program
   for (int v = 0; v < 4; ++v) build_schedule(c, v & 1, v & 2);
   c->op_ev.assign(n_ops, nullptr);

@@ -418,6 +418,10 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     float* sl = slot0 + h * ACRMI_SLOT + ACRMI_SLOT_POSES + 3 * j;
     sl[0] = aa[0]; sl[1] = aa[1]; sl[2] = aa[2];
   }
+  if (a.poison && *a.poison) {      // (uniform) invalid program results: NaN everywhere instead of plausible numbers
+    __syncthreads();
+    for (int i = tid; i < 2 * ACRMI_SLOT; i += 256) slot0[i] = __builtin_nanf("");
+  }
 }
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, s, a);

@@ -55,6 +55,8 @@ struct ConvArgs {
   int splitk;
   float* split_ws;
   unsigned* split_cnt;
+  unsigned* range_flag;   // conv_x3 / conv_x3p with f16 halves: set to 1 when an activation beyond the f16 range was split
+                          // (null: not tracked - the stand-alone operator calls)
 };
 // workspace of a split-K launch: (8x16-pixel tiles) x (32-cout blocks) groups of `splits` partial tiles of 4096 floats
 inline size_t conv_splitk_groups(int B, int Ho, int Wo, int cout) {
@@ -152,6 +154,8 @@ struct DecodeArgs {
   int B;
   float* slots;
   float thresh;          // centermap_conf_thresh (acr/result_parser.py:241), strict >
+  const unsigned* poison; // non-null and != 0 on the device: the program's results are invalid (fp16x3 range overflow) - every
+                         // slot is written as NaN, so that MANO's meshes are NaN too instead of plausible numbers
   const int* prior_gate; // null: the cross-hand prior is decided per frame (both hands found, centers <= 32 px apart);
                          // else [B]: < 0 = per frame, 0 = no prior, 1 = prior whenever the frame has both hands (the caller
                          // has applied the reference's batch-wide rules, acr/result_parser.py:42-47,131)

@@ -279,6 +279,13 @@ class Engine(object):
         _lib.check(self.L.acrmi_backbone_heads(self.ctx, _ptr(img), B, _stream(self.device)), self.ctx)
         return B
 
+    def check_range(self):
+        """'fp16x3' programs: waits for the current stream and raises _lib.AcrmiRangeError if an activation left the f16
+        range (|x| > 65504) since the last check - the split halves are then inf / -inf and the library has written the
+        affected calls' slots and meshes as NaN (acrmi_check_range).  A no-op for every other precision.  Engine.forward
+        stays asynchronous and does NOT call this; the host-facing API (acr.model.ACR.forward, acr.main.ACR) does."""
+        _lib.check(self.L.acrmi_check_range(self.ctx, _stream(self.device)), self.ctx)
+
     def heads(self, features):
         """acr/model.py:47-65 on backbone features the caller holds: float [B, C0, 128, 128] (NCHW, what the reference's
         head_forward takes; C0 = 32 for HRNet-W32) -> the heads run on them, results as after backbone_heads (head_maps /

@@ -124,13 +124,14 @@ def split16(x, dt=DT_F16):
 
 
 def x3_weight_shift(ws):
-    """Power-of-two pre-scaling of an op's filters for conv_x3_kernel: S with max |w| 2^S in [2^12, 2^13) (0 <= S <= 30), so
+    """Power-of-two pre-scaling of an op's filters for conv_x3_kernel: S with max |w| 2^S in [2^12, 2^13) (-30 <= S <= 30), so
     that lo = f16(w 2^S - hi) stays a NORMAL f16 number for every |w| >= 2^-16 max |w| (unscaled, a weight below 2^-3 has
-    its lo in the f16 subnormals: an absolute error of up to 3e-8 instead of 2^-22 |w|)."""
+    its lo in the f16 subnormals: an absolute error of up to 3e-8 instead of 2^-22 |w|) - and, S < 0, so that folded filters
+    ABOVE the f16 range (|w| >= 2^13 already shifts down) never become inf halves."""
     m = max(float(np.max(np.abs(w))) for w in ws)
     if not np.isfinite(m) or m <= 0.0:
         return 0
-    return int(min(30, max(0, 12 - int(np.floor(np.log2(m))))))
+    return int(min(30, max(-30, 12 - int(np.floor(np.log2(m))))))
 
 
 def pack_conv_x3(wb_list, dt=DT_F16):

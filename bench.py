@@ -769,8 +769,18 @@ def main():
         dom = [p for p in prof if p['kind'] == L.OP_CONV and p['ksize'] == 3 and p['stride'] == 1]
         dom_ms = sum(p['ms'] for p in dom)
         dom_flops = sum(p['flops'] for p in dom) * B
-        conv_ms = sum(p['ms'] for p in prof if p['kind'] in (L.OP_CONV, L.OP_STEM))
+        # convolutions = OP_CONV + the uint8 stem + layer1's fused 1x1 pairs (OP_PAIR1X1: conv3 64->256 + residual chained with
+        # the next conv1 256->64 - two convolutions in one launch; r4's line counted them as "not convolution")
+        conv_kinds = (L.OP_CONV, L.OP_STEM, L.OP_PAIR1X1)
+        conv_ms = sum(p['ms'] for p in prof if p['kind'] in conv_kinds)
         total_ms = sum(p['ms'] for p in prof)
+        kind_names = {L.OP_FUSESUM: 'hr_fuse_sum', L.OP_BILINEAR2X: 'bilinear2x', L.OP_POW11: 'cam_pow', L.OP_ATTPOOL: 'attention_pool',
+                      L.OP_PAREBIAS: 'pare_bias', L.OP_MAXPOOL: 'maxpool', L.OP_U8NORM: 'u8norm', L.OP_POINTHEADS: 'point_heads'}
+        non_conv = {}
+        for p in prof:
+            if p['kind'] not in conv_kinds:
+                k = kind_names.get(p['kind'], 'kind%d' % p['kind'])
+                non_conv[k] = non_conv.get(k, 0.0) + p['ms']
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         # `achieved` here counts ALGORITHMIC (direct-convolution) FLOPs; Winograd executes 2.25x (1.5x) fewer of them
         # on the matrix pipe, so this figure can exceed the MFMA peak (reported as algorithmic_* below).
@@ -807,7 +817,10 @@ def main():
                     'algorithmic_gflop_per_launch': round(dom_flops / max(1, len(dom)) / 1e9, 2),
                     'share_of_step_ms': round(dom_ms / total_ms, 3),
                     'whole_path_frac': round(fps / world * GFLOP_PER_FRAME * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-                    'all_conv_ms': round(conv_ms, 3), 'all_ops_ms': round(total_ms, 3)}
+                    'all_conv_ms': round(conv_ms, 3), 'all_ops_ms': round(total_ms, 3),
+                    'non_conv_ms': dict({k: round(v, 3) for k, v in sorted(non_conv.items())}, total=round(total_ms - conv_ms, 3),
+                                        note='single-stream HIP-event times of the ops that are not convolutions (decode + MANO run '
+                                             'behind the program: ~0.18 ms more)')}
         out = {'metric': 'frames/sec (2-hand mesh) at 512x512 batch-64; vertex L2 vs ref', 'value': round(fps, 2),
                'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

@@ -30,6 +30,7 @@ extern "C" {
 #define ACRMI_EHIP (-2)    /* HIP runtime error                                              */
 #define ACRMI_ESTATE (-3)  /* call order violated (weights/program/MANO tables not loaded)   */
 #define ACRMI_ENOMEM (-4)
+#define ACRMI_ERANGE (-5)  /* an 'fp16x3' program met an activation outside the f16 range (acrmi_check_range) */
 
 typedef struct acrmi_ctx acrmi_ctx;
 
@@ -193,6 +194,12 @@ int acrmi_decode(acrmi_ctx* ctx, int B, float* slots_dev, void* stream);
  * batch is set; :42-47: determine_coeff reads row 0 of each side's list) - acr/result_parser.py ResultParser(batch_semantics=
  * 'reference') decodes once, applies those batch-wide rules to the flags / centers, and decodes again with the gate. */
 int acrmi_decode_gated(acrmi_ctx* ctx, int B, const int32_t* prior_gate_dev, float* slots_dev, void* stream);
+/* 'fp16x3' programs (fp32 tensors, operands split into two f16 numbers - conv algo 6): an activation with |x| > 65504 cannot
+ * be split (hi = inf).  The split kernels track it per launch at one v_max3 per two values; while the flag is set acrmi_decode /
+ * acrmi_forward write every slot as NaN (so the meshes are NaN too: nothing plausible-looking leaves the library).  This call
+ * waits for `stream`, returns ACRMI_ERANGE if the flag was set since the last check and clears it; ACRMI_OK otherwise and for
+ * programs without split-f16 convolutions (fp32, bf16x3: fp32's exponent range). */
+int acrmi_check_range(acrmi_ctx* ctx, void* stream);
 
 /* Same decode on caller-supplied NHWC maps (unit tests / callers with their own maps):
  * center [B,64,64,center_cs] (ch 0), params [B,64,64,params_cs] (109 ch), prior (106 ch). */

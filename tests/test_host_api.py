@@ -307,6 +307,13 @@ def test_split16_and_pack_conv_x3_layout():
     np.testing.assert_array_equal(bp[:40], b.astype(np.float32))
     # the weight scale: zero / non-finite filters fall back to no scaling; grouped ops share ONE scale (the largest group decides)
     assert packer.x3_weight_shift([np.zeros((32, 32, 3, 3))]) == 0 and packer.x3_weight_shift([np.full((32, 32, 1, 1), np.inf)]) == 0
+    # folded filters above the f16 range shift DOWN: no inf halves, the kernel's inverse scale stays exact
+    big = np.random.RandomState(3).normal(0, 1, (32, 32, 3, 3)) * 3e6
+    sb = packer.x3_weight_shift([big])
+    assert sb < 0 and 2.0 ** 12 <= np.abs(big).max() * 2.0 ** sb < 2.0 ** 13
+    pb, _ = packer.pack_conv_x3([(big, np.zeros(32))])
+    halves = pb[:-1].view(np.uint16).view(np.float16)
+    assert np.isfinite(halves.astype(np.float32)).all() and pb[-1] == np.float32(2.0 ** -sb)
     pg, bg = packer.pack_conv_x3([(w[:32], b[:32]), (w[:32] * 2.0 ** -6, b[:32])], packer.DT_BF16)
     assert pg.size == 2 * 9 * (32 // 8) * 256 + 1 and pg[-1] == np.float32(2.0 ** -packer.x3_weight_shift([w[:32]])) and bg.size == 64
     assert packer.conv_algo(3, 1, 64, 64, 1, 64, 64, split16=True) == 6 and packer.conv_algo(3, 1, 64, 64, 1, 64, 64) == 4
