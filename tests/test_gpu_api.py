@@ -74,7 +74,8 @@ def test_manolayer_surface(mano_tables):
     with pytest.raises(ValueError):
         ML(side='right', use_pca=False, root_rot_mode='rotmat', tables=mano_tables['right'])     # (broken in the reference too)
     with pytest.raises(ValueError):
-        ML(side='right', use_pca=False, joint_rot_mode='rotmat', tables=mano_tables['right'])
+        ML(side='right', use_pca=False, joint_rot_mode='quat', tables=mano_tables['right'])      # ('axisang' | 'rotmat')
+    assert ML(side='right', use_pca=False, joint_rot_mode='rotmat', tables=mano_tables['right']).joint_rot_mode == 'rotmat'
     with pytest.raises(FileNotFoundError):
         ML(side='left', use_pca=False, mano_root='/nonexistent/')
 
