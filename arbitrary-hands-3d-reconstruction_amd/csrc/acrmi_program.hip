@@ -82,6 +82,11 @@ int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStrea
       a.cin8 = (op.cin + 7) / 8;
       a.n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       a.bias_fstride = op.bias_per_frame ? desc(op.aux_buf).cs : 0;
+      a.nxt = op.nterms;      // extra residual terms of a stride-2 convolution (the HR fuse folded into its epilogue)
+      for (int t = 0; t < op.nterms && t < 3; ++t) {
+        a.xt[t] = ptr(op.term_buf[t]);
+        a.xt_cs[t] = desc(op.term_buf[t]).cs; a.xt_coff[t] = op.term_coff[t]; a.xt_shift[t] = op.term_shift[t];
+      }
       a.algo = op.flags & 7;
       a.range_flag = a.algo == 6 ? c->range_flag : nullptr;      // f16 operand halves: |x| must stay inside the f16 range
       a.dtype = di.dtype;                                    // 16-bit input: conv_h16.hip
@@ -197,7 +202,11 @@ static void op_rw(const acrmi_ctx* c, const acrmi_op& op, std::vector<int>& R, s
   auto w = [&](int id) { if (id >= 0) W.push_back(id); };
   switch (op.kind) {
     case ACRMI_OP_U8NORM: case ACRMI_OP_STEM: w(op.out_buf); break;
-    case ACRMI_OP_CONV: r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf); w(op.out_buf); break;
+    case ACRMI_OP_CONV:
+      r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf);
+      for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]);
+      w(op.out_buf);
+      break;
     case ACRMI_OP_FUSESUM: for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]); w(op.out_buf); break;
     case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: r(op.in_buf); w(op.out_buf); break;
     case ACRMI_OP_PAIR1X1: r(op.in_buf); r(op.res_buf); w(op.out_buf); w(op.aux_buf); break;
@@ -383,6 +392,20 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
         if (splitk || op.res_buf >= 0 || idt || algo == 3 || !w_ok(op.w_off2, (long long)bufs[op.out_buf].h * bufs[op.out_buf].w * mcs))
           return fail(c, ACRMI_EINVAL, "op %d: a position-bias map needs an fp32 conv without a residual buffer (not algo 3) and "
                       "[Ho][Wo][round4(groups*Cout)] floats inside the blob at w_off2", i);
+      }
+      if (op.nterms) {      // extra residual terms (ConvArgs.xt): what conv_pp2_kernel<1, true> / the 32-cout stride-2 kernel take
+        const int ho_ = bufs[op.out_buf].h, wo_ = bufs[op.out_buf].w;
+        if (op.nterms < 0 || op.nterms > 3 || idt || op.ksize != 3 || op.stride != 2 || (algo != 0 && algo != 5) || splitk ||
+            (op.flags & ACRMI_CONV_BIAS_MAP) || op.cout % 32 || op.cin <= 16 || op.out_coff % 4 || bufs[op.out_buf].cs % 4)
+          return fail(c, ACRMI_EINVAL, "op %d: extra residual terms need an fp32 3x3 stride-2 convolution (algo 0 / 5) with Cin > 16, "
+                      "Cout %% 32 = 0 and 16-byte aligned output channels", i);
+        for (int t = 0; t < op.nterms; ++t) {
+          const int tb = op.term_buf[t];
+          if (!buf_ok(tb) || bufs[tb].dtype != ACRMI_DT_F32 || op.term_coff[t] < 0 || op.term_coff[t] % 4 || bufs[tb].cs % 4 ||
+              op.term_shift[t] < 0 || op.term_shift[t] > 3 || op.term_coff[t] + op.groups * op.cout > bufs[tb].cs ||
+              (bufs[tb].h << op.term_shift[t]) != ho_ || (bufs[tb].w << op.term_shift[t]) != wo_ || tb == op.out_buf)
+            return fail(c, ACRMI_EINVAL, "op %d: residual term %d does not fit the output", i, t);
+        }
       }
       if (op.bias_per_frame && buf_ok(op.aux_buf) && bufs[op.aux_buf].dtype != ACRMI_DT_F32)
         return fail(c, ACRMI_EINVAL, "op %d: the per-frame bias must be fp32", i);

@@ -568,6 +568,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.splitk && a.algo != 2) return hipErrorInvalidValue;
+  if (a.nxt > 0 && a.algo != 5 && a.algo != 0) return hipErrorInvalidValue;      // extra residual terms: stride-2 kernels only
   if ((a.algo == 6 || a.algo == 7) && a.ks == 1) return launch_x3p(a, a.algo == 7, s);      // ... 1x1 (conv_x3p.inc)
   if (a.algo == 6 || a.algo == 7) return launch_x3(a, a.algo == 7, s);      // 3x3 stride 1, split f16 / bf16 operands on the 16-bit matrix pipe (conv_x3.inc)
   if (a.algo == 5) return launch_pp2(a, s);     // 3x3 stride 2, polyphase + F(2,2): weights packed with 4 x 7 taps (conv_pp2.inc)
@@ -601,6 +602,10 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
     // (the previous round's kernel; the program lowers every 3x3 stride-1 conv to algo 2 now)
     if (n32) return small ? launch_wino<8, 16, 2, 1, 32, 2>(a, s) : launch_wino<16, 16, 4, 1, 32, 2>(a, s);
     return launch_wino<8, 16, 2, 2, 32, 2>(a, s);
+  }
+  if (a.nxt > 0) {      // extra residual terms (HR fuse): the polyphase kernel above, or the 32-cout stride-2 direct kernel
+    if (a.ks != 3 || a.stride != 2 || a.cin8 * 8 <= 16 || a.nxt > 3) return hipErrorInvalidValue;
+    return launch_ws2_impl<3, 2, 8, 16, 4, 1, 1, 1, 16, 2, false, true>(a, s);
   }
   // direct: template arguments <KS, S, TH, TW, WAVES_M, MT, WAVES_N, NTW, CK, NLW>
   if (a.ks == 3 && a.stride == 1) {

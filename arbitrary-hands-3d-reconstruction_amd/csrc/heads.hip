@@ -324,27 +324,46 @@ struct CenterPick {
 };
 struct PickScratch {
   float cmap[2][64 * 64];
+  float rmax[64 * 64];        // 5-wide row maximum of one hand's cmap (the 5x5 window maximum = its 5-high column maximum)
   float bestv[2][4];
   int besti[2][4];
 };
 __device__ inline void pick_centers(const float* const* center, int center_cs, int b, float thresh, PickScratch& sc,
                                     CenterPick& pk, const int* prior_gate = nullptr) {
   const int tid = threadIdx.x;
-  for (int h = 0; h < 2; ++h)
-    for (int i = tid; i < 4096; i += 256) sc.cmap[h][i] = center[h][((size_t)b * 4096 + i) * center_cs];
+  {
+    // channel 0 of the two center maps: 2 x 16 strided reads per thread, ALL requested before the first one is used (a frame
+    // is one workgroup: with the loads issued one per loop trip their latencies added up to most of the kernel's 55 us)
+    float v[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[h][k] = center[h][((size_t)b * 4096 + tid + 256 * k) * center_cs];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sc.cmap[h][tid + 256 * k] = v[h][k];
+  }
   __syncthreads();
+  // 5x5 window maximum, separably (max is exact and associative: the same value as the 25-element maximum)
   for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();     // the other hand's row maxima have been read
+    for (int i = tid; i < 4096; i += 256) {
+      const int x = i & 63;
+      float m = sc.cmap[h][i];
+      for (int dx = -2; dx <= 2; ++dx)
+        if (dx != 0 && x + dx >= 0 && x + dx < 64) m = fmaxf(m, sc.cmap[h][i + dx]);
+      sc.rmax[i] = m;
+    }
+    __syncthreads();
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < 4096; i += 256) {
-      const int y = i >> 6, x = i & 63;
+      const int y = i >> 6;
       const float v = sc.cmap[h][i];
-      float m = v;
+      float m = sc.rmax[i];
       for (int dy = -2; dy <= 2; ++dy)
-        for (int dx = -2; dx <= 2; ++dx) {
-          const int yy = y + dy, xx = x + dx;
-          if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) m = fmaxf(m, sc.cmap[h][yy * 64 + xx]);
-        }
+        if (dy != 0 && y + dy >= 0 && y + dy < 64) m = fmaxf(m, sc.rmax[i + dy * 64]);
       const float det = (m == v) ? v : v * 0.f;      // x * (maxpool(x) == x)  (acr/result_parser.py:245-249)
       if (det > bv || (det == bv && i < bi)) { bv = det; bi = i; }
     }

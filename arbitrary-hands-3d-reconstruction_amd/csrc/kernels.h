@@ -55,6 +55,14 @@ struct ConvArgs {
   int splitk;
   float* split_ws;
   unsigned* split_cnt;
+  // Extra residual terms (the HR-module fuse, acr/model.py:672-686, folded into the epilogue of the downsampling chain's
+  // last convolution): out = [relu]((conv + bias + res) + up(xt[0]) + up(xt[1]) + up(xt[2])), summed in this order; term t
+  // is a [B][Ho >> shift][Wo >> shift][xt_cs] map read at pixel (y >> shift, x >> shift) = nearest-neighbour upsampling,
+  // channels [xt_coff, xt_coff + groups * Cout).  3x3 stride-2 convolutions only (conv_pp2_kernel<1, true>, the 32-cout
+  // conv_ws2_kernel), Cout % 32 == 0, 16-byte aligned channel slices.
+  int nxt;
+  const float* xt[3];
+  int xt_cs[3], xt_coff[3], xt_shift[3];
   unsigned* range_flag;   // conv_x3 / conv_x3p with f16 halves: set to 1 when an activation beyond the f16 range was split
                           // (null: not tracked - the stand-alone operator calls)
 };
@@ -219,6 +227,9 @@ struct ManoArgs {
   const float* offsets; int off_div;   // offsets row = hand row / off_div
   float *verts_camed, *pj2d, *pj2d_org;
   int lbs_f16;                         // blend-shape tables and skinning weights from their f16 copies
+  int slices;                          // workgroups per hand (launch_mano sets it): slice s computes pose blend, skinning and
+                                       // outputs of vertices [s * ceil(778 / slices), ...) - everything before the pose blend
+                                       // (rotations, shape blend, joint regression, chain) is cheap and repeated per slice
   int pose_rotmat;                     // 1: `poses` rows are 16 row-major 3x3 rotation matrices (joint_rot_mode='rotmat',
                                        // mano/manolayer.py:151-162): no Rodrigues, no hands_mean
 };

@@ -21,7 +21,13 @@ constexpr int NV = 778, NV3 = 2334;
 // product and sum stays fp32; v_template, the joint regressor and the kinematic chain are untouched.
 template <bool H16>
 __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // a.slices workgroups per hand (launch_mano): at small batches a hand's 120 us - one CU streaming the 1.26 MB pose-blend
+  // table - are on the call's critical path; the slices split that table by vertex range.  Every vertex and joint is
+  // computed by exactly one slice with the arithmetic of the one-workgroup form: results do not depend on a.slices.
+  const int row = blockIdx.x / a.slices, slice = blockIdx.x - row * a.slices;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vper = (NV + a.slices - 1) / a.slices;
+  const int v0 = slice * vper, v1 = v0 + vper < NV ? v0 + vper : NV;
   const int side = a.side ? a.side[row] : (row & 1);
   const ManoTables& T = a.t[side];
   __shared__ float sR[16][9];
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
   }
   __syncthreads();
   // pose blend (needs v_shaped complete for the regression above, so done after it)
-  for (int i = tid; i < NV3; i += 256) {
+  for (int i = 3 * v0 + tid; i < 3 * v1; i += 256) {
     float s = 0.f;
     for (int k = 0; k < 135; ++k)
       s += (H16 ? (float)__builtin_bit_cast(_Float16, T.posedirs_h[k * NV3 + i]) : T.posedirs_t[k * NV3 + i]) * sPoseMap[k];
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
   }
   __syncthreads();
   // linear blend skinning (mano/manolayer.py:230-240)
-  for (int v = tid; v < NV; v += 256) {
+  for (int v = v0 + tid; v < v1; v += 256) {
     float Tm[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) Tm[e] = 0.f;
@@ -168,13 +174,16 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
       lty = of[2] - of[6];      // crop_trbl[0] - pad_trbl[0]
     }
   }
-  for (int i = tid; i < NV3; i += 256) {
+  for (int i = 3 * v0 + tid; i < 3 * v1; i += 256) {
     const int d = i % 3;
     const float v = sV[i] - (d == 0 ? cx : (d == 1 ? cy : cz));
     a.verts[(size_t)row * NV3 + i] = v;
     if (proj && a.verts_camed) a.verts_camed[(size_t)row * NV3 + i] = d == 2 ? v : v * cs + (d == 0 ? ctx : cty);
   }
-  if (tid < 63) {
+  // joint j: a chain joint is written by slice 0, a fingertip by the slice that skinned its vertex
+  const int jsrc = tid < 63 ? c_reorder[tid / 3] : 0;
+  const int jtip = jsrc >= 16 ? c_tips[side][jsrc - 16] : -1;
+  if (tid < 63 && (jtip < 0 ? slice == 0 : (jtip >= v0 && jtip < v1))) {
     const int j = tid / 3, d = tid % 3;
     const float v = sJtr[j][d] - (d == 0 ? cx : (d == 1 ? cy : cz));
     a.joints[(size_t)row * 63 + tid] = v;
@@ -185,16 +194,22 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
         a.pj2d_org[(size_t)row * 42 + j * 2 + d] = (pj + 1.f) * (d == 0 ? padw : padh) / 2.f + (d == 0 ? ltx : lty);
     }
   }
-  if (a.center && tid < 3) a.center[(size_t)row * 3 + tid] = sCenter[tid];
+  if (a.center && tid < 3 && slice == 0) a.center[(size_t)row * 3 + tid] = sCenter[tid];
 }
 
-hipError_t launch_mano(const ManoArgs& a, hipStream_t s) {
-  if (a.H <= 0) return hipSuccess;
+hipError_t launch_mano(const ManoArgs& a0, hipStream_t s) {
+  if (a0.H <= 0) return hipSuccess;
+  ManoArgs a = a0;
+  // workgroups per hand: enough to give every CU one (2 hands: 8 slices; 128 hands: 2).  A root joint that is a FINGERTIP
+  // (center_idx 4, 8, 12, 16, 20: a skinned vertex, mano/manolayer.py:241-262) is known only to the slice that skinned
+  // it: one slice then.
+  const bool tip_center = a.center_idx >= 0 && a.center_idx % 4 == 0 && a.center_idx > 0;
+  a.slices = tip_center ? 1 : (a.H >= 256 ? 1 : (256 / a.H > 8 ? 8 : 256 / a.H));
   if (a.lbs_f16) {
     if (!a.t[0].posedirs_h || !a.t[1].posedirs_h) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mano_kernel<true>, dim3(a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mano_kernel<true>, dim3(a.H * a.slices), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(mano_kernel<false>, dim3(a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mano_kernel<false>, dim3(a.H * a.slices), dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

@@ -403,6 +403,11 @@ def splitk_slices(k, stride, cin, cout, groups, ho, wo, per_frame_bias):
     return 1
 
 
+# HR-module fuse sums of the lower resolutions in the epilogue of the x0 chain's last stride-2 convolution (Program.hr_module);
+# ACRMI_FUSE_EPI=0 keeps every sum an OP_FUSESUM launch (A/B runs)
+FUSE_EPILOGUE = __import__('os').environ.get('ACRMI_FUSE_EPI', '1') != '0'
+
+
 # layer1.0's projection shortcut as extra input channels of its last 1x1 conv (Program.bottleneck): batch 64, fp32:
 # downsample 0.46 ms + conv3 0.51 ms -> one 128 -> 256 conv.
 FUSE_PROJECTION = True
@@ -523,9 +528,11 @@ class Program(object):
         return op
 
     def conv(self, name, src, wb_list, k, stride, relu, out=None, out_c=None, in_coff=0, out_coff=0, res=None,
-             res_coff=0, cin=None, bias_buf=None, bias_map=None):
+             res_coff=0, cin=None, bias_buf=None, bias_map=None, terms=None):
         """wb_list: [(w, b)] one entry per group (all same shape).  bias_map: [Ho,Wo,round4(groups*Cout)] added to every
-        frame before the ReLU (ACRMI_CONV_BIAS_MAP; fp32 programs, no residual)."""
+        frame before the ReLU (ACRMI_CONV_BIAS_MAP; fp32 programs, no residual).  terms: [(buf, shift)] up to three extra
+        residual maps at 1 / 2^shift of the output size, added behind `res` before the ReLU in this order (fp32 3x3
+        stride-2 convolutions: the HR fuse sum in the epilogue of the x0 downsampling chain, fuse_epilogue_ok)."""
         h, w_, _ = self.dims(src)
         cout, cin_w = wb_list[0][0].shape[:2]
         cin = cin_w if cin is None else cin
@@ -580,6 +587,14 @@ class Program(object):
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
         if slices > 1:
             self.ops[-1].flags = algo | _lib.CONV_SPLITK
+        if terms:
+            assert len(terms) <= 3 and self.dt == DT_F32 and k == 3 and stride == 2 and algo in (0, 5) and len(wb_list) == 1
+            op = self.ops[-1]
+            op.nterms = len(terms)
+            for t, (tb, sh) in enumerate(terms):
+                th, tw, tcs = self.dims(tb)
+                assert (th << sh, tw << sh) == (ho, wo) and tcs >= cout and tb != out
+                op.term_buf[t], op.term_coff[t], op.term_shift[t] = tb, 0, sh
         if bias_map is not None:
             assert res is None and self.dt == DT_F32 and algo != 3
             assert bias_map.shape == (ho, wo, (cout * len(wb_list) + 3) // 4 * 4), bias_map.shape
@@ -608,7 +623,8 @@ class Program(object):
             fam = 'conv_h16_kernel'
         self.op_info[-1]['kernel'] = fam
         self.op_info[-1]['bytes'] = float(h * w_ * cin * ng * esz(src) + ho * wo * (cout if slices > 1 else cout * ng) * esz(out) *
-                                          (2 if res is not None else 1))
+                                          (2 if res is not None else 1) +
+                                          sum((ho >> sh) * (wo >> sh) * cout * 4 for (_, sh) in (terms or [])))
         if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
             self.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for (w, b) in wb_list]
         return out
@@ -616,6 +632,12 @@ class Program(object):
     def cp(self, c):
         """channel count of a backbone-internal map that logically holds c channels (pad_channels)"""
         return self.chan_pad.get(c, c)
+
+    def fuse_epilogue_ok(self, cin, cout):
+        """The HR-module fuse sum of an output resolution i >= 1 runs in the epilogue of the last convolution of its x0
+        downsampling chain (3x3 stride 2, no ReLU of its own: acr/model.py:641-666) instead of as an OP_FUSESUM launch: fp32
+        storage (the 16-bit storage programs' kernel has no such epilogue), Cin > 16, Cout a multiple of 32."""
+        return FUSE_EPILOGUE and self.dt == DT_F32 and cin > 16 and cin % 8 == 0 and cout % 32 == 0
 
     def conv_bn(self, src, conv, bn, k, stride, relu, padded=False, **kw):
         """padded: a backbone-internal convolution - its filters are zero-padded to the padded channel counts of its input and
@@ -728,7 +750,11 @@ class Program(object):
             x = y
 
     def hr_module(self, xs, p, ch, multi_scale=True, final_out=None):
-        """acr/model.py:668-686.  xs consumed; returns the fused outputs."""
+        """acr/model.py:668-686.  xs consumed; returns the fused outputs.  Sum order = the reference's (j ascending):
+        y_i = (((t_i0 + t_i1) + t_i2) + t_i3), ReLU.  For i >= 1 the first term is the x0 downsampling chain's output: where
+        fuse_epilogue_ok, that chain's last convolution takes the other terms as extra residuals and the ReLU, and writes
+        y_i itself - bit for bit what OP_FUSESUM computes from the stored conv output, one launch and one round trip of
+        the map through HBM less."""
         nb = len(xs)
         xs = list(xs)
         for i in range(nb):
@@ -736,25 +762,40 @@ class Program(object):
                 xs[i] = self.basic_block(xs[i], '%s.branches.%d.%d' % (p, i, k))
         outs = []
         temps = []
+
+        def term(i, j, hosted=None):
+            """fuse_layers[i][j] applied to xs[j] -> (buffer, shift); hosted: the extra terms the LAST conv of a j < i chain
+            adds in its epilogue (it then writes the fused map, ReLU included)"""
+            f = '%s.fuse_layers.%d.%d' % (p, i, j)
+            if j == i:
+                return xs[j], 0
+            if j > i:
+                t = self.conv_bn(xs[j], f + '.0', f + '.1', 1, 1, False, padded=True)
+                temps.append(t)
+                return t, j - i
+            t = xs[j]
+            for k in range(i - j):
+                last = k == i - j - 1
+                kw = dict(terms=hosted) if (last and hosted) else {}
+                t2 = self.conv_bn(t, '%s.%d.0' % (f, k), '%s.%d.1' % (f, k), 3, 2, (not last) or bool(hosted), padded=True, **kw)
+                if t is not xs[j]:
+                    self.release(t)
+                t = t2
+            if not hosted:
+                temps.append(t)
+            return t, 0
+
         for i in range(nb if multi_scale else 1):
-            terms = []
-            for j in range(nb):
-                f = '%s.fuse_layers.%d.%d' % (p, i, j)
-                if j == i:
-                    terms.append((xs[j], 0))
-                elif j > i:
-                    t = self.conv_bn(xs[j], f + '.0', f + '.1', 1, 1, False, padded=True)
-                    terms.append((t, j - i))
-                    temps.append(t)
-                else:
-                    t = xs[j]
-                    for k in range(i - j):
-                        t2 = self.conv_bn(t, '%s.%d.0' % (f, k), '%s.%d.1' % (f, k), 3, 2, k != i - j - 1, padded=True)
-                        if t is not xs[j]:
-                            self.release(t)
-                        t = t2
-                    terms.append((t, 0))
-                    temps.append(t)
+            f0 = '%s.fuse_layers.%d.0' % (p, i)
+            if i >= 1 and final_out is None:
+                wl = self.sd['%s.%d.0.weight' % (f0, i - 1)]      # the chain's last conv: [C_i, C_0, 3, 3]
+                if self.fuse_epilogue_ok(self.cp(wl.shape[1]), self.cp(wl.shape[0])):
+                    others = [term(i, j) for j in range(1, nb)]
+                    y, _ = term(i, 0, hosted=others)
+                    self.op_info[-1]['name'] += '+fuse%d' % i
+                    outs.append(y)
+                    continue
+            terms = [term(i, j) for j in range(nb)]
             # fuse_sum wants the full-resolution term first for geometry; keep the reference's sum order
             # (j ascending) by letting the kernel take per-term shifts.
             if terms[0][1] != 0:

@@ -111,8 +111,11 @@ typedef struct {
   int64_t w_off, b_off;                   /* float offsets into the weight blob              */
   int32_t bias_per_frame;                 /* 1: bias comes from aux buffer, row per frame    */
   int32_t aux_buf;                        /* PAREBIAS/ATTPOOL output or per-frame bias input */
-  int32_t nterms;                         /* FUSESUM */
-  int32_t term_buf[4], term_coff[4], term_shift[4];
+  int32_t nterms;                         /* FUSESUM: 1..4 terms.  CONV (fp32 3x3 stride 2, Cout % 32 = 0): 0..3 EXTRA residual terms */
+  int32_t term_buf[4], term_coff[4], term_shift[4];   /* added behind res_buf and before the ReLU, in this order, term t read
+                                             at pixel (y >> shift, x >> shift) of a map 1 / 2^shift the output's size (nearest
+                                             upsampling): the HR-module fuse sum (acr/model.py:672-686) in the epilogue of the
+                                             x0 downsampling chain's last convolution */
   int64_t w_off2, b_off2, w_off3;         /* PAREBIAS: linear weights/bias, mix-conv pare columns */
   int32_t flags;                          /* CONV: algo 0..7 (bits 0-2) | ACRMI_CONV_BIAS_MAP; PAREBIAS: part slice start
                                              (0 right / 16 left); POINTHEADS: side (0 left / 1 right) */

@@ -15,7 +15,9 @@ op by op, in torch-CPU arithmetic on the un-packed folded filters the packer kee
   * the lowering's own constructions are read back into the convolutions they stand for: a CONV with ACRMI_CONV_SPLITK is
     ONE convolution over its concatenated K-slices, ACRMI_CONV_BIAS_MAP adds the position-bias map of the blob to every
     frame, PAIR1X1 is two 1x1 convolutions (64 -> 256 + residual + ReLU, then 256 -> 64 + ReLU), MAXPOOL and the 7x7 stem
-    belong to the build-defined ResNet-50 (oracle/acr_net.resnet50_backbone).
+    belong to the build-defined ResNet-50 (oracle/acr_net.resnet50_backbone); a CONV with nterms > 0 adds that many extra
+    residual maps (nearest-upsampled by 2^shift) before its ReLU: the HR-module fuse sum (acr/model.py:672-686) folded into
+    the last convolution of the x0 downsampling chain.
 
 For fp32 W32 programs the same interpreter is cross-checked against oracle/acr_net.py (pinned to the reference), which
 pins the interpreter's reading of the op list; tests/test_program_oracle.py.
@@ -82,6 +84,12 @@ class Interp(object):
             y = y + self.blob[op.w_off2:op.w_off2 + ho * wo * cs].view(1, ho, wo, cs)[..., :n]
         if op.res_buf >= 0:
             y = y + self.bufs[op.res_buf][..., op.res_coff:op.res_coff + n]
+        for t in range(op.nterms):                     # extra residual terms: the HR fuse sum in this conv's epilogue
+            v = self.bufs[op.term_buf[t]][..., op.term_coff[t]:op.term_coff[t] + n]
+            sh = op.term_shift[t]
+            if sh:
+                v = v.repeat_interleave(1 << sh, 1).repeat_interleave(1 << sh, 2)    # nearest up (acr/model.py:639)
+            y = y + v
         if op.relu:
             y = torch.relu(y)
         self.bufs[op.out_buf][..., op.out_coff:op.out_coff + n] = rnd(y, self.dts[op.out_buf])
