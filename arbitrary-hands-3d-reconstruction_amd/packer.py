@@ -281,6 +281,9 @@ def polyphase2_weights(w):
 POLYPHASE2 = __import__('os').environ.get('ACRMI_PP2', '1') != '0'
 
 
+POLYPHASE2_SMALL = __import__('os').environ.get('ACRMI_PP2_SMALL', '1') != '0'      # ... also in small-batch programs (A/B: 0)
+
+
 def polyphase2_ok(cin, cout, ho, wo):
     """conv_pp2_kernel takes the layer (csrc/conv_pp2.inc pp2_ok; ho, wo = OUTPUT map, the input is twice that)."""
     return cin % 16 == 0 and cout % 32 == 0 and ho % 8 == 0 and wo % 16 == 0
@@ -335,7 +338,10 @@ def conv_algo(k, stride, cin, cout, groups=1, ho=0, wo=0, per_frame_bias=False, 
     if split16 and split16_ok(k, stride, cin, cout, ho, wo):
         return 7 if split16 == 'bf16' else 6
     if k == 3 and stride == 2:
-        big = WINOGRAD_24 if wino24 is None else wino24       # (the large-batch lowering: items of 8x16 output pixels)
+        # round 4 took the polyphase kernel for the large-batch lowering only; its items (8x16 output pixels x 32 or 64 couts)
+        # are no fewer than the direct kernel's at small batches and run 25 products per 2x2 block instead of 36: the 24
+        # stride-2 launches on a batch-1 call's dependency chain were 22.8 us each as direct convolutions (tools/critical_path.py)
+        big = (WINOGRAD_24 if wino24 is None else wino24) or POLYPHASE2_SMALL
         return 5 if (POLYPHASE2 and big and polyphase2_ok(cin, cout, ho, wo)) else 0
     if not (WINOGRAD and use_winograd(k, stride)):
         return 0
