@@ -90,7 +90,8 @@ def validate(ns):
         raise ValueError("batch_semantics %r: 'frame' or 'reference'" % (ns.batch_semantics,))
     if ns.model_precision not in ('fp32', 'fp16', 'bf16', 'fp16x3', 'bf16x3'):
         # acr/config.py:96: fp32 (configs/demo.yml) | fp16 (the argparse default: autocast, acr/model.py:33-37);
-        # bf16 = the same 16-bit program on the other gfx950 MFMA type (packer.lower)
+        # bf16 = the same 16-bit program on the other gfx950 MFMA type (packer.lower); fp16x3 / bf16x3 = fp32 tensors with
+        # split 16-bit operands (fp32-class accuracy; fp16x3 needs |activation| <= 65504 and reports ACRMI_ERANGE otherwise)
         raise ValueError("model_precision %r: 'fp32', 'fp16', 'bf16', 'fp16x3' or 'bf16x3'" % ns.model_precision)
     return ns
 

@@ -56,8 +56,12 @@ class Engine(object):
                         wino24='auto', splitk='auto'):
         """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
         keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`).
-        precision: 'fp32' | 'fp16' | 'bf16' (args().model_precision, acr/config.py:96; packer.lower) | 'fp16x3' (fp32 storage,
-        split-f16 operands on the 16-bit matrix pipe for the 3x3 stride-1 layers: csrc/conv_x3.inc).
+        precision: 'fp32' | 'fp16' | 'bf16' (args().model_precision, acr/config.py:96; packer.lower) | 'fp16x3' / 'bf16x3' (fp32
+        storage, operands split into two f16 / bf16 numbers on the 16-bit matrix pipe for the 3x3 and 1x1 stride-1 layers:
+        csrc/conv_x3.inc).  'fp16x3' has the f16 RANGE: every activation must stay within |x| <= 65504 - a checkpoint that
+        exceeds it makes the affected calls return NaN slots / meshes and `check_range()` raise AcrmiRangeError (the
+        host-facing API calls it); 'bf16x3' has fp32's range at 16-bit operand precision (8e-6 m instead of 1e-6 m on the
+        bench frames)
         wino24: 'auto' (F(2x4,3x3) for contexts of max_batch >= 16), True / False to force (packer.lower).
         splitk: 'auto' (split-K lowering of the low-resolution 3x3 layers for contexts of max_batch < 16), True / False."""
         # F(2x4,3x3) is a large-batch choice: its items (8x32 pixels x one n-tile) are half as many as conv_wino2's
