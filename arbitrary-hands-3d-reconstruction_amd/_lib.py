@@ -11,6 +11,7 @@ OP_MAXPOOL, OP_PAIR1X1 = 11, 12
 MODE_BOTH, MODE_DENSE, MODE_POINT = 0, 1, 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV / acrmi_conv2d's algo: ACRMI_CONV_BIAS_MAP
 CONV_SPLITK = 16       # acrmi_op.flags of a CONV: ACRMI_CONV_SPLITK
+CONV_DUAL = 32         # acrmi_op.flags of a CONV: ACRMI_CONV_DUAL (second output = the full-resolution HR fuse sum)
 OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF, OPT_MANO_FP16 = 1, 2, 3, 4, 5, 6, 7
 OPT_LANE_PLAN = 8
 VERSION = 302

@@ -87,6 +87,9 @@ int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStrea
         a.xt[t] = ptr(op.term_buf[t]);
         a.xt_cs[t] = desc(op.term_buf[t]).cs; a.xt_coff[t] = op.term_coff[t]; a.xt_shift[t] = op.term_shift[t];
       }
+      if (op.flags & ACRMI_CONV_DUAL) {      // the full-resolution HR fuse sum as a second output (conv_wino3's store waves)
+        a.out2 = ptr(op.aux_buf); a.out2_cs = desc(op.aux_buf).cs; a.out2_coff = 0;
+      }
       a.algo = op.flags & 7;
       a.range_flag = a.algo == 6 ? c->range_flag : nullptr;      // f16 operand halves: |x| must stay inside the f16 range
       a.dtype = di.dtype;                                    // 16-bit input: conv_h16.hip
@@ -206,6 +209,7 @@ static void op_rw(const acrmi_ctx* c, const acrmi_op& op, std::vector<int>& R, s
       r(op.in_buf); r(op.res_buf); if (op.bias_per_frame) r(op.aux_buf);
       for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]);
       w(op.out_buf);
+      if (op.flags & ACRMI_CONV_DUAL) w(op.aux_buf);
       break;
     case ACRMI_OP_FUSESUM: for (int t = 0; t < op.nterms; ++t) r(op.term_buf[t]); w(op.out_buf); break;
     case ACRMI_OP_BILINEAR2X: case ACRMI_OP_MAXPOOL: r(op.in_buf); w(op.out_buf); break;
@@ -393,17 +397,24 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
           return fail(c, ACRMI_EINVAL, "op %d: a position-bias map needs an fp32 conv without a residual buffer (not algo 3) and "
                       "[Ho][Wo][round4(groups*Cout)] floats inside the blob at w_off2", i);
       }
+      const bool dual = (op.flags & ACRMI_CONV_DUAL) != 0;
+      if (dual && (algo != 3 || op.nterms < 1 || op.bias_per_frame || !buf_ok(op.aux_buf) || bufs[op.aux_buf].dtype != ACRMI_DT_F32 ||
+                   bufs[op.aux_buf].h != bufs[op.out_buf].h || bufs[op.aux_buf].w != bufs[op.out_buf].w || bufs[op.aux_buf].cs % 4 ||
+                   bufs[op.aux_buf].cs < op.cout || op.aux_buf == op.out_buf || op.aux_buf == op.in_buf || op.aux_buf == op.res_buf))
+        return fail(c, ACRMI_EINVAL, "op %d: a second output needs algo 3, 1..3 terms and an fp32 map of the output's size in aux_buf", i);
       if (op.nterms) {      // extra residual terms (ConvArgs.xt): what conv_pp2_kernel<1, true> / the 32-cout stride-2 kernel take
         const int ho_ = bufs[op.out_buf].h, wo_ = bufs[op.out_buf].w;
-        if (op.nterms < 0 || op.nterms > 3 || idt || op.ksize != 3 || op.stride != 2 || (algo != 0 && algo != 5) || splitk ||
-            (op.flags & ACRMI_CONV_BIAS_MAP) || op.cout % 32 || op.cin <= 16 || op.out_coff % 4 || bufs[op.out_buf].cs % 4)
+        if (op.nterms < 0 || op.nterms > 3 || idt || (op.flags & ACRMI_CONV_BIAS_MAP) || splitk ||
+            (dual ? false : (op.ksize != 3 || op.stride != 2 || (algo != 0 && algo != 5) || op.cout % 32 || op.cin <= 16 ||
+                             op.out_coff % 4 || bufs[op.out_buf].cs % 4)))
           return fail(c, ACRMI_EINVAL, "op %d: extra residual terms need an fp32 3x3 stride-2 convolution (algo 0 / 5) with Cin > 16, "
-                      "Cout %% 32 = 0 and 16-byte aligned output channels", i);
+                      "Cout %% 32 = 0 and 16-byte aligned output channels - or ACRMI_CONV_DUAL", i);
         for (int t = 0; t < op.nterms; ++t) {
           const int tb = op.term_buf[t];
           if (!buf_ok(tb) || bufs[tb].dtype != ACRMI_DT_F32 || op.term_coff[t] < 0 || op.term_coff[t] % 4 || bufs[tb].cs % 4 ||
               op.term_shift[t] < 0 || op.term_shift[t] > 3 || op.term_coff[t] + op.groups * op.cout > bufs[tb].cs ||
-              (bufs[tb].h << op.term_shift[t]) != ho_ || (bufs[tb].w << op.term_shift[t]) != wo_ || tb == op.out_buf)
+              (bufs[tb].h << op.term_shift[t]) != ho_ || (bufs[tb].w << op.term_shift[t]) != wo_ || tb == op.out_buf ||
+              (dual && tb == op.aux_buf))
             return fail(c, ACRMI_EINVAL, "op %d: residual term %d does not fit the output", i, t);
         }
       }

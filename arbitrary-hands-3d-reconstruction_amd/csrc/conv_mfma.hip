@@ -568,7 +568,8 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   const bool n32 = a.n_tiles == 1;
   const bool small = (a.Ho * a.Wo <= 256) || (a.Ho % 16 != 0) || (a.Wo % 16 != 0);
   if (a.splitk && a.algo != 2) return hipErrorInvalidValue;
-  if (a.nxt > 0 && a.algo != 5 && a.algo != 0) return hipErrorInvalidValue;      // extra residual terms: stride-2 kernels only
+  if (a.nxt > 0 && a.algo != 5 && a.algo != 0 && !(a.algo == 3 && a.out2)) return hipErrorInvalidValue;      // extra residual terms: the stride-2 kernels, or conv_wino3's second output
+  if (a.out2 && a.algo != 3) return hipErrorInvalidValue;
   if ((a.algo == 6 || a.algo == 7) && a.ks == 1) return launch_x3p(a, a.algo == 7, s);      // ... 1x1 (conv_x3p.inc)
   if (a.algo == 6 || a.algo == 7) return launch_x3(a, a.algo == 7, s);      // 3x3 stride 1, split f16 / bf16 operands on the 16-bit matrix pipe (conv_x3.inc)
   if (a.algo == 5) return launch_pp2(a, s);     // 3x3 stride 2, polyphase + F(2,2): weights packed with 4 x 7 taps (conv_pp2.inc)

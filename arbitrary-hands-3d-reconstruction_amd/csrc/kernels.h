@@ -63,6 +63,11 @@ struct ConvArgs {
   int nxt;
   const float* xt[3];
   int xt_cs[3], xt_coff[3], xt_shift[3];
+  // ACRMI_CONV_DUAL (conv_wino3_kernel with store waves only): `out` stays the convolution's own output (bias, residual, ReLU);
+  // the xt terms are NOT added to it but to a SECOND output, out2 = relu(((out + up(xt[0])) + up(xt[1])) + up(xt[2])) - the
+  // full-resolution HR fuse sum, whose first term (branch 0's last conv2) is also read by the downsampling chains
+  float* out2;
+  int out2_cs, out2_coff;
   unsigned* range_flag;   // conv_x3 / conv_x3p with f16 halves: set to 1 when an activation beyond the f16 range was split
                           // (null: not tracked - the stand-alone operator calls)
 };

@@ -412,6 +412,8 @@ def splitk_slices(k, stride, cin, cout, groups, ho, wo, per_frame_bias):
 # HR-module fuse sums of the lower resolutions in the epilogue of the x0 chain's last stride-2 convolution (Program.hr_module);
 # ACRMI_FUSE_EPI=0 keeps every sum an OP_FUSESUM launch (A/B runs)
 FUSE_EPILOGUE = __import__('os').environ.get('ACRMI_FUSE_EPI', '1') != '0'
+# ... and the full-resolution sum as the second output of branch 0's last conv2 (Program.fuse0_ok); ACRMI_FUSE_EPI0=0: a launch
+FUSE_FULLRES = __import__('os').environ.get('ACRMI_FUSE_EPI0', '1') != '0'
 
 
 # layer1.0's projection shortcut as extra input channels of its last 1x1 conv (Program.bottleneck): batch 64, fp32:
@@ -534,11 +536,13 @@ class Program(object):
         return op
 
     def conv(self, name, src, wb_list, k, stride, relu, out=None, out_c=None, in_coff=0, out_coff=0, res=None,
-             res_coff=0, cin=None, bias_buf=None, bias_map=None, terms=None):
+             res_coff=0, cin=None, bias_buf=None, bias_map=None, terms=None, dual=None):
         """wb_list: [(w, b)] one entry per group (all same shape).  bias_map: [Ho,Wo,round4(groups*Cout)] added to every
         frame before the ReLU (ACRMI_CONV_BIAS_MAP; fp32 programs, no residual).  terms: [(buf, shift)] up to three extra
         residual maps at 1 / 2^shift of the output size, added behind `res` before the ReLU in this order (fp32 3x3
-        stride-2 convolutions: the HR fuse sum in the epilogue of the x0 downsampling chain, fuse_epilogue_ok)."""
+        stride-2 convolutions: the HR fuse sum in the epilogue of the x0 downsampling chain, fuse_epilogue_ok).
+        dual: (out2, [(buf, shift)]) - ACRMI_CONV_DUAL: `out` gets the convolution as usual, out2 = relu(out + the terms) - the
+        full-resolution HR fuse sum written by conv_wino3_kernel's store waves (algo 3 only, fuse0_ok)."""
         h, w_, _ = self.dims(src)
         cout, cin_w = wb_list[0][0].shape[:2]
         cin = cin_w if cin is None else cin
@@ -593,8 +597,14 @@ class Program(object):
                  bias_per_frame=0 if bias_buf is None else 1, aux_buf=-1 if bias_buf is None else bias_buf)
         if slices > 1:
             self.ops[-1].flags = algo | _lib.CONV_SPLITK
+        if dual:
+            out2, terms = dual
+            assert algo == 3 and bias_buf is None and self.dims(out2)[:2] == (ho, wo) and out2 != out
+            self.ops[-1].flags = algo | _lib.CONV_DUAL
+            self.ops[-1].aux_buf = out2
         if terms:
-            assert len(terms) <= 3 and self.dt == DT_F32 and k == 3 and stride == 2 and algo in (0, 5) and len(wb_list) == 1
+            assert len(terms) <= 3 and self.dt == DT_F32 and len(wb_list) == 1
+            assert dual or (k == 3 and stride == 2 and algo in (0, 5))
             op = self.ops[-1]
             op.nterms = len(terms)
             for t, (tb, sh) in enumerate(terms):
@@ -630,7 +640,8 @@ class Program(object):
         self.op_info[-1]['kernel'] = fam
         self.op_info[-1]['bytes'] = float(h * w_ * cin * ng * esz(src) + ho * wo * (cout if slices > 1 else cout * ng) * esz(out) *
                                           (2 if res is not None else 1) +
-                                          sum((ho >> sh) * (wo >> sh) * cout * 4 for (_, sh) in (terms or [])))
+                                          sum((ho >> sh) * (wo >> sh) * cout * 4 for (_, sh) in (terms or [])) +
+                                          (ho * wo * cout * 4 if dual else 0))
         if self.keep_weights:    # folded fp64 filters per group, for oracle/program.py (tests only)
             self.op_info[-1]['wb'] = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for (w, b) in wb_list]
         return out
@@ -677,12 +688,24 @@ class Program(object):
         return out
 
     # ---- blocks ------------------------------------------------------------------------------
-    def basic_block(self, x, p):
-        """acr/model.py:483-499; consumes x (released), returns the new buffer."""
+    def basic_block(self, x, p, dual=None):
+        """acr/model.py:483-499; consumes x (released), returns the new buffer.  dual: see conv() - conv2 also writes the
+        HR fuse sum that starts with this block's output."""
         t = self.conv_bn(x, p + '.conv1', p + '.bn1', 3, 1, True, padded=True)
-        y = self.conv_bn(t, p + '.conv2', p + '.bn2', 3, 1, True, res=x, padded=True)
+        kw = dict(dual=dual) if dual else {}
+        y = self.conv_bn(t, p + '.conv2', p + '.bn2', 3, 1, True, res=x, padded=True, **kw)
         self.release(t, x)
         return y
+
+    def fuse0_ok(self, c, h, w):
+        """The FULL-resolution HR fuse sum as the second output of branch 0's last conv2 (ACRMI_CONV_DUAL): where that conv runs
+        on conv_wino3_kernel (algo 3: fp32, 32 channels, with its store waves) - in LARGE-batch programs only.  The host conv
+        has to wait for the other branches' 1x1 projections, so x0 - which the three downsampling chains read - appears later
+        than it would from a plain conv2: free where launches fill the chip (batch 64: 1962 -> 1999 frames/s), but on the
+        dependency chain of a single-frame call (batch 1: 2.69 -> 2.90 ms with it, measured) - small-batch programs keep the
+        OP_FUSESUM launch for i = 0."""
+        return (FUSE_EPILOGUE and FUSE_FULLRES and self.dt == DT_F32 and not self.splitk and
+                conv_algo(3, 1, self.cp(c), self.cp(c), 1, h, w, False, self.wino24, self.split16) == 3)
 
     def bottleneck(self, x, p, cat=None, stride=1):
         """acr/model.py:519-539.  stride 2 (ResNet-50 only, torchvision's layout): on the 3x3 conv and on the 1x1
@@ -763,8 +786,10 @@ class Program(object):
         the map through HBM less."""
         nb = len(xs)
         xs = list(xs)
+        h0, w0, _ = self.dims(xs[0])
+        fold0 = nb > 1 and self.fuse0_ok(ch[0], h0, w0)
         for i in range(nb):
-            for k in range(4):
+            for k in range(3 if (i == 0 and fold0) else 4):
                 xs[i] = self.basic_block(xs[i], '%s.branches.%d.%d' % (p, i, k))
         outs = []
         temps = []
@@ -793,6 +818,15 @@ class Program(object):
 
         for i in range(nb if multi_scale else 1):
             f0 = '%s.fuse_layers.%d.0' % (p, i)
+            if i == 0 and fold0:
+                # branch 0's last block: its conv2 writes x0 (the downsampling chains read it) AND, from the store waves,
+                # y0 = relu(((x0 + up(t01)) + up(t02)) + up(t03)) - the 1x1-projected lower branches are computed first
+                others = [term(0, j) for j in range(1, nb)]
+                y0 = final_out if final_out is not None else self.buf(h0, w0, self.cp(ch[0]))
+                xs[0] = self.basic_block(xs[0], '%s.branches.0.3' % p, dual=(y0, others))
+                self.op_info[-1]['name'] += '+fuse0'
+                outs.append(y0)
+                continue
             if i >= 1 and final_out is None:
                 wl = self.sd['%s.%d.0.weight' % (f0, i - 1)]      # the chain's last conv: [C_i, C_0, 3, 3]
                 if self.fuse_epilogue_ok(self.cp(wl.shape[1]), self.cp(wl.shape[0])):

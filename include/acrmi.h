@@ -94,6 +94,12 @@ enum {
  * results).  cin % 32 == 0, cin >= 64, 2 <= groups <= 8.  What it is for: a 256 -> 256 layer on a 16x16 map is 16 work
  * items of 8 chunks for 256 CUs at batch 1 - 64 items of 2 chunks with 4 slices. */
 #define ACRMI_CONV_SPLITK 16
+/* acrmi_op.flags of a CONV, bit 5: second output (algo 3 only: 3x3 stride 1, Cin <= 32, Cout = 32).  out_buf receives the
+ * convolution as usual (bias, residual, ReLU); the op's nterms extra maps are NOT added to it but to a second map:
+ * aux_buf = relu(((out + up(term 0)) + up(term 1)) + up(term 2)), each term read at (y >> shift, x >> shift).  This is the
+ * HR-module fuse sum of the FULL resolution (acr/model.py:672-686, i = 0): its first term, the output of branch 0's last
+ * conv2, is also the input of the downsampling chains, so both maps are needed.  Bit-equal to the ACRMI_OP_FUSESUM launch. */
+#define ACRMI_CONV_DUAL 32
 
 /* acrmi_op.mode: which variant of the head program an op belongs to. */
 enum {

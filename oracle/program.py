@@ -33,6 +33,7 @@ OP_MAXPOOL, OP_PAIR1X1 = 11, 12
 MODE_POINT = 2
 CONV_BIAS_MAP = 8      # acrmi_op.flags of a CONV (include/acrmi.h)
 CONV_SPLITK = 16
+CONV_DUAL = 32
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 
@@ -84,12 +85,20 @@ class Interp(object):
             y = y + self.blob[op.w_off2:op.w_off2 + ho * wo * cs].view(1, ho, wo, cs)[..., :n]
         if op.res_buf >= 0:
             y = y + self.bufs[op.res_buf][..., op.res_coff:op.res_coff + n]
+        dual = bool(op.flags & CONV_DUAL)              # the terms go into a SECOND output (aux_buf), not into this one
+        if dual:
+            if op.relu:
+                y = torch.relu(y)
+            self.bufs[op.out_buf][..., op.out_coff:op.out_coff + n] = rnd(y, self.dts[op.out_buf])
         for t in range(op.nterms):                     # extra residual terms: the HR fuse sum in this conv's epilogue
             v = self.bufs[op.term_buf[t]][..., op.term_coff[t]:op.term_coff[t] + n]
             sh = op.term_shift[t]
             if sh:
                 v = v.repeat_interleave(1 << sh, 1).repeat_interleave(1 << sh, 2)    # nearest up (acr/model.py:639)
             y = y + v
+        if dual:
+            self.bufs[op.aux_buf][..., :n] = rnd(torch.relu(y), self.dts[op.aux_buf])
+            return
         if op.relu:
             y = torch.relu(y)
         self.bufs[op.out_buf][..., op.out_coff:op.out_coff + n] = rnd(y, self.dts[op.out_buf])

@@ -544,7 +544,9 @@ def test_fuse_sum_in_the_conv_epilogue_is_bit_equal_to_the_fuse_sum_launch(lower
     batches, the 32-cout stride-2 direct kernel at small ones; up to three extra residual maps, nearest-upsampled by
     2^shift, summed in the reference's order, then the ReLU).  The same fp32 operations in the same order as the
     OP_FUSESUM launch on the stored conv output: the backbone output and EVERY head map of the program with the fold are
-    BIT-EQUAL to the program without it (15 launches fewer per pass)."""
+    BIT-EQUAL to the program without it.  The eight FULL-resolution sums (i = 0) are the second output of branch 0's last conv2,
+    written by conv_wino3_kernel's store waves (ACRMI_CONV_DUAL; large-batch fp32 W32 programs): 23 launches fewer per pass there,
+    15 in the small-batch / W48 / split-operand programs."""
     packer, L = pkg('packer'), pkg('_lib')
     synth = pkg('synth')
     sd = synth_sd if not lowering.startswith('w48') else synth.make_state_dict(seed=0, width=48)
@@ -554,6 +556,8 @@ def test_fuse_sum_in_the_conv_epilogue_is_bit_equal_to_the_fuse_sum_launch(lower
     x = torch.from_numpy(np.concatenate([frames2, frames2[:1]])).cuda()
     res = {}
     saved = packer.FUSE_EPILOGUE
+    # the full-resolution sums ride on conv_wino3_kernel's store waves (ACRMI_CONV_DUAL): fp32 HRNet-W32 programs
+    full = 8 if lowering == 'large' else 0      # (large-batch fp32 W32 programs: packer.Program.fuse0_ok)
     try:
         for fold in (True, False):
             packer.FUSE_EPILOGUE = fold
@@ -562,7 +566,8 @@ def test_fuse_sum_in_the_conv_epilogue_is_bit_equal_to_the_fuse_sum_launch(lower
             ops = eng.program['ops']
             hosted = sum(1 for o in ops if o.kind == L.OP_CONV and o.nterms)
             sums = sum(1 for o in ops if o.kind == L.OP_FUSESUM)
-            assert (hosted, sums) == ((15, 8) if fold else (0, 23)), (hosted, sums)
+            assert (hosted, sums) == ((15 + full, 8 - full) if fold else (0, 23)), (hosted, sums)
+            assert sum(1 for o in ops if o.kind == L.OP_CONV and o.flags & L.CONV_DUAL) == (full if fold else 0)
             B = eng.backbone_heads(x)
             torch.cuda.synchronize()
             maps = {k: v.clone() for k, v in eng.head_maps(B).items()}

@@ -329,7 +329,12 @@ def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
     """'fp16x3' lowers to the SAME op list, buffers and biases as 'fp32' - only the eligible 3x3 and 1x1 stride-1 convolutions
     change their kernel (algo 6) and weight packing."""
     packer, L = pkg('packer'), pkg('_lib')
-    p32 = packer.lower(synth_sd, precision='fp32', point_heads=False)
+    saved = packer.FUSE_FULLRES      # (the full-resolution fuse sum as conv_wino3's second output exists in the fp32 program only:
+    packer.FUSE_FULLRES = False      #  branch 0's convolutions are conv_x3 launches in the split-operand program)
+    try:
+        p32 = packer.lower(synth_sd, precision='fp32', point_heads=False)
+    finally:
+        packer.FUSE_FULLRES = saved
     px3 = packer.lower(synth_sd, precision='fp16x3', point_heads=False)
     assert px3['bufs'] == p32['bufs'] and len(px3['ops']) == len(p32['ops'])
     n6 = 0
