@@ -641,16 +641,30 @@ def test_malformed_programs_are_rejected(synth_sd):
         heads = L.HeadLayout.from_buffer_copy(bytes(prog['heads']))
         mutate(ops, heads)
         return L.lib().acrmi_set_program(eng.ctx, bufs, len(bufs), ops, len(ops), C.byref(heads), 1)
-    fuse = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_FUSESUM)
     conv = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_CONV and o.ksize == 3)
+    # round 5: the HR fuse sums of the large-batch program are extra residual terms of convolutions (nterms / term_buf) and the
+    # second output of branch 0's last conv2 (ACRMI_CONV_DUAL, aux_buf): the same checks apply to them
+    hosted = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_CONV and o.nterms and not (o.flags & L.CONV_DUAL))
+    dual = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_CONV and o.flags & L.CONV_DUAL)
+    fuse = hosted
 
     def set_(i, field, val):
         return lambda ops, heads: setattr(ops[i], field, val)
 
     def term(ops, heads):
-        ops[fuse].term_buf[1] = len(prog['bufs']) + 3
+        ops[fuse].term_buf[0] = len(prog['bufs']) + 3
     stem = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_STEM)
-    cases_ = [term, set_(conv, 'w_off', blob.size - 8), set_(conv, 'in_buf', -1), set_(conv, 'out_coff', 4096),
+    def term_shift(ops, heads):
+        ops[hosted].term_shift[0] = ops[hosted].term_shift[0] + 1      # the term's map no longer fits the output
+
+    def dual_alias(ops, heads):
+        ops[dual].aux_buf = ops[dual].out_buf
+
+    def dual_on_other_kernel(ops, heads):
+        ops[hosted].flags = ops[hosted].flags | L.CONV_DUAL              # a second output needs algo 3
+
+    cases_ = [term, term_shift, dual_alias, dual_on_other_kernel, set_(dual, 'aux_buf', -1), set_(hosted, 'nterms', 4),
+              set_(conv, 'nterms', 1), set_(conv, 'w_off', blob.size - 8), set_(conv, 'in_buf', -1), set_(conv, 'out_coff', 4096),
               set_(conv, 'cin', 4096), set_(conv, 'b_off', -5), set_(conv, 'mode', 7), set_(conv, 'ksize', 5),
               set_(stem, 'cout', 32), set_(stem, 'w_off', blob.size - 100), set_(stem, 'out_coff', 2),
               lambda ops, heads: heads.center_buf.__setitem__(0, 999),
@@ -659,6 +673,15 @@ def test_malformed_programs_are_rejected(synth_sd):
         assert try_program(m) == L.E_INVAL
         assert L.lib().acrmi_last_error(eng.ctx)
     assert try_program(lambda ops, heads: None) == 0           # the untouched program still loads
+    eng.close()
+    # ... and the small-batch program's OP_FUSESUM terms
+    prog = packer.lower(synth_sd, wino24=False, splitk=True)
+    eng = pkg('engine').Engine(0)
+    blob = prog['blob']
+    L.check(L.lib().acrmi_load_weights(eng.ctx, blob.ctypes.data_as(C.c_void_p), blob.size), eng.ctx)
+    bufs = (L.BufferDesc * len(prog['bufs']))(*[L.BufferDesc(*b) for b in prog['bufs']])
+    fuse = next(i for i, o in enumerate(prog['ops']) if o.kind == L.OP_FUSESUM)
+    assert try_program(term) == L.E_INVAL and try_program(lambda ops, heads: None) == 0
     eng.close()
 
 
