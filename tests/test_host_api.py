@@ -373,3 +373,37 @@ def test_x3_weight_scale_sits_where_the_kernel_reads_it_for_every_op(synth_sd, p
         seen += 1
         point += op.mode == L.MODE_POINT
     assert seen >= 190 and point == 4      # the four center-tower convs of the point-heads variant carry their own packs
+
+
+@pytest.mark.parametrize('lowering', ['large', 'small', 'fp16x3', 'fp16'])
+def test_hr_fuse_sums_are_lowered_exactly_once_each(synth_sd, lowering):
+    """acr/model.py:672-686: HRNet-W32 has 23 fuse sums (stage 2: 2, stage 3: 4 x 3, stage 4: 2 x 4 + 1).  Round 5 lowers them as
+    (a) extra residual terms of the x0 downsampling chain's last stride-2 convolution (output resolutions i >= 1), (b) the second
+    output of branch 0's last conv2 (i = 0, large-batch fp32 programs: ACRMI_CONV_DUAL) or (c) an OP_FUSESUM launch - every sum
+    exactly once, with terms of the right geometry, in the reference's order (branch index ascending)."""
+    packer, L = pkg('packer'), pkg('_lib')
+    kw = {'large': {}, 'small': dict(wino24=False, splitk=True), 'fp16x3': dict(precision='fp16x3'), 'fp16': dict(precision='fp16')}[lowering]
+    prog = packer.lower(synth_sd, point_heads=False, **kw)
+    ops, info, bufs = prog['ops'], prog['op_info'], prog['bufs']
+    hosted = [(o, i) for o, i in zip(ops, info) if o.kind == L.OP_CONV and o.nterms and not (o.flags & L.CONV_DUAL)]
+    dual = [(o, i) for o, i in zip(ops, info) if o.kind == L.OP_CONV and (o.flags & L.CONV_DUAL)]
+    sums = [(o, i) for o, i in zip(ops, info) if o.kind == L.OP_FUSESUM]
+    want = {'large': (15, 8, 0), 'small': (15, 0, 8), 'fp16x3': (15, 0, 8), 'fp16': (0, 0, 23)}[lowering]
+    assert (len(hosted), len(dual), len(sums)) == want
+    for o, i in hosted:          # 3x3 stride 2, ReLU of the fuse, terms at the output's resolution >> shift, distinct buffers
+        assert o.ksize == 3 and o.stride == 2 and o.relu == 1 and '+fuse' in i['name'] and 1 <= o.nterms <= 3
+        ho, wo = bufs[o.out_buf][:2]
+        seen = {o.out_buf, o.in_buf}
+        for t in range(o.nterms):
+            th, tw, tcs = bufs[o.term_buf[t]][:3]
+            assert (th << o.term_shift[t], tw << o.term_shift[t]) == (ho, wo) and tcs >= o.cout and o.term_buf[t] not in seen
+            seen.add(o.term_buf[t])
+        # same-resolution terms (branches j <= i) come before the upsampled ones (j > i), shifts ascending: branch order
+        shifts = [o.term_shift[t] for t in range(o.nterms)]
+        assert shifts == sorted(shifts)
+    for o, i in dual:            # branch 0's last conv2: residual block output + the upsampled projections of the lower branches
+        assert (o.flags & 7) == 3 and o.res_buf >= 0 and o.relu == 1 and i['name'].endswith('conv2+fuse0')
+        assert bufs[o.aux_buf][:2] == bufs[o.out_buf][:2] and o.aux_buf not in (o.out_buf, o.in_buf, o.res_buf)
+        assert [o.term_shift[t] for t in range(o.nterms)] == list(range(1, o.nterms + 1))
+    for o, i in sums:
+        assert o.relu == 1 and 2 <= o.nterms <= 4
