@@ -335,7 +335,10 @@ int acrmi_check_range(acrmi_ctx* c, void* stream) {
   HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
   HIPCHK(c, hipMemcpy(&v, c->range_flag, sizeof(v), hipMemcpyDeviceToHost));
   if (!v) return ACRMI_OK;
-  HIPCHK(c, hipMemset(c->range_flag, 0, sizeof(v)));
+  // cleared ON the caller's stream (the streams of acrmi_stream_create are non-blocking: a null-stream memset is not ordered
+  // against work the caller queues next and could wipe a later launch's flag), then waited for
+  HIPCHK(c, hipMemsetAsync(c->range_flag, 0, sizeof(v), (hipStream_t)stream));
+  HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
   return fail(c, ACRMI_ERANGE, "an activation of the 'fp16x3' program left the f16 range (|x| > 65504): its split halves are "
                                "inf / -inf and the results since the last check are invalid (slots and meshes were written as "
                                "NaN); use precision 'bf16x3' or 'fp32' for this checkpoint");
@@ -385,6 +388,26 @@ int acrmi_mano_rotmat(acrmi_ctx* c, const float* rotmats, const float* betas, in
   return ACRMI_OK;
 }
 
+// The last op that writes the backbone map (heads.backbone_buf) and the channels it leaves there: an op whose out_buf is the
+// map - or, in large-batch fp32 programs, the ACRMI_CONV_DUAL convolution whose SECOND output (aux_buf: the full-resolution HR
+// fuse sum of the last stage, written at channel 0) is the map.  first = the op behind it (-1: none), c0 = channels.
+static void backbone_writer(const acrmi_ctx* c, int* first, int* c0) {
+  const int bb = c->heads.backbone_buf;
+  *first = -1;
+  *c0 = 0;
+  for (int i = 0; i < (int)c->ops.size(); ++i) {
+    const acrmi_op& op = c->ops[i];
+    if (op.kind == ACRMI_OP_COORDFILL) continue;
+    if (op.out_buf == bb) {
+      *first = i + 1;
+      *c0 = op.out_coff + op.cout * (op.kind == ACRMI_OP_CONV ? op.groups : 1);
+    } else if (op.kind == ACRMI_OP_CONV && (op.flags & ACRMI_CONV_DUAL) && op.aux_buf == bb) {
+      *first = i + 1;
+      *c0 = op.cout;
+    }
+  }
+}
+
 int acrmi_heads(acrmi_ctx* c, const float* feat_nchw, int B, void* stream) {
   if (!c || !feat_nchw) return fail(c, ACRMI_EINVAL, "acrmi_heads: bad arguments");
   if (!c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_heads: no program");
@@ -396,11 +419,7 @@ int acrmi_heads(acrmi_ctx* c, const float* feat_nchw, int B, void* stream) {
                                  "fp32-storage programs (fp32, fp16x3, bf16x3)");
   // the head ops = everything behind the last op that writes the backbone map (acr/model.py:47: head_forward starts there)
   int first = -1, c0 = 0;
-  for (int i = 0; i < (int)c->ops.size(); ++i)
-    if (c->ops[i].kind != ACRMI_OP_COORDFILL && c->ops[i].out_buf == bb) {
-      first = i + 1;
-      c0 = c->ops[i].out_coff + c->ops[i].cout * (c->ops[i].kind == ACRMI_OP_CONV ? c->ops[i].groups : 1);
-    }
+  backbone_writer(c, &first, &c0);
   if (first < 0 || c0 <= 0 || c0 > d.cs) return fail(c, ACRMI_ESTATE, "acrmi_heads: the program has no backbone output op");
   ON_DEVICE(c);
   HIPCHK(c, launch_nchw_to_nhwc(feat_nchw, B, c0, d.h, d.w, c->buf_ptr[bb], d.cs, 0, (hipStream_t)stream));
@@ -409,10 +428,8 @@ int acrmi_heads(acrmi_ctx* c, const float* feat_nchw, int B, void* stream) {
 
 int acrmi_backbone_channels(acrmi_ctx* c) {
   if (!c || !c->have_program) return fail(c, ACRMI_ESTATE, "acrmi_backbone_channels: no program");
-  const int bb = c->heads.backbone_buf;
-  int c0 = 0;
-  for (const acrmi_op& op : c->ops)
-    if (op.kind != ACRMI_OP_COORDFILL && op.out_buf == bb) c0 = op.out_coff + op.cout * (op.kind == ACRMI_OP_CONV ? op.groups : 1);
+  int first = -1, c0 = 0;
+  backbone_writer(c, &first, &c0);
   return c0;
 }
 

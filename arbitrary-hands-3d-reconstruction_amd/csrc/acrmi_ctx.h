@@ -41,7 +41,7 @@ struct acrmi_ctx {
   std::string err;
   float* weights = nullptr;     // the packed blob on the device - owned, or another context's (acrmi_share_weights)
   size_t n_weights = 0;
-  std::atomic<int>* weights_ref = nullptr;   // host-side use count of `weights` shared by the contexts that hold it (null: no blob)
+  std::atomic<int>* weights_ref = nullptr;   // host-side use count of `weights` shared by the contexts that hold it (null: no blob).  Atomic so that contexts may be DESTROYED from different threads; acrmi_share_weights(c, donor) against a concurrent destroy / reload of the donor is NOT safe (the count could reach 0 between its read and its increment): callers serialize those (engine.EnginePool builds its contexts on one thread)
   std::vector<acrmi_buffer_desc> bufs;
   std::vector<float*> buf_ptr;
   std::vector<acrmi_op> ops;

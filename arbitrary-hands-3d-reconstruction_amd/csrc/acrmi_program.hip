@@ -402,7 +402,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
                    bufs[op.aux_buf].h != bufs[op.out_buf].h || bufs[op.aux_buf].w != bufs[op.out_buf].w || bufs[op.aux_buf].cs % 4 ||
                    bufs[op.aux_buf].cs < op.cout || op.aux_buf == op.out_buf || op.aux_buf == op.in_buf || op.aux_buf == op.res_buf))
         return fail(c, ACRMI_EINVAL, "op %d: a second output needs algo 3, 1..3 terms and an fp32 map of the output's size in aux_buf", i);
-      if (op.nterms) {      // extra residual terms (ConvArgs.xt): what conv_pp2_kernel<1, true> / the 32-cout stride-2 kernel take
+      if (op.nterms) {      // extra residual terms (ConvArgs.xt): what conv_pp2_kernel<NT, true> / the 32-cout stride-2 kernel take
         const int ho_ = bufs[op.out_buf].h, wo_ = bufs[op.out_buf].w;
         if (op.nterms < 0 || op.nterms > 3 || idt || (op.flags & ACRMI_CONV_BIAS_MAP) || splitk ||
             (dual ? false : (op.ksize != 3 || op.stride != 2 || (algo != 0 && algo != 5) || op.cout % 32 || op.cin <= 16 ||

@@ -58,7 +58,7 @@ struct ConvArgs {
   // Extra residual terms (the HR-module fuse, acr/model.py:672-686, folded into the epilogue of the downsampling chain's
   // last convolution): out = [relu]((conv + bias + res) + up(xt[0]) + up(xt[1]) + up(xt[2])), summed in this order; term t
   // is a [B][Ho >> shift][Wo >> shift][xt_cs] map read at pixel (y >> shift, x >> shift) = nearest-neighbour upsampling,
-  // channels [xt_coff, xt_coff + groups * Cout).  3x3 stride-2 convolutions only (conv_pp2_kernel<1, true>, the 32-cout
+  // channels [xt_coff, xt_coff + groups * Cout).  3x3 stride-2 convolutions only (conv_pp2_kernel<1, true> / <2, true>, the 32-cout
   // conv_ws2_kernel), Cout % 32 == 0, 16-byte aligned channel slices.
   int nxt;
   const float* xt[3];

@@ -161,7 +161,9 @@ void acrmi_destroy(acrmi_ctx* ctx);
 int acrmi_load_weights(acrmi_ctx* ctx, const float* blob_host, size_t n_floats);
 /* The same blob for several contexts of one device (a pool of contexts that take batches in turn): `ctx` uses
  * the device copy `donor` holds instead of uploading its own - 330 MB per extra context at HRNet-W32 fp32.  The copy is freed
- * when the last context holding it is destroyed or loads other weights.  Both contexts need the same program. */
+ * when the last context holding it is destroyed or loads other weights.  Both contexts need the same program.  Thread safety:
+ * contexts sharing a blob may be destroyed from different threads; this call itself must not run concurrently with a destroy or
+ * a weight reload of `donor` (serialize them in the host). */
 int acrmi_share_weights(acrmi_ctx* ctx, acrmi_ctx* donor);
 
 /* Lowered topology of acr/model.py:785-865 + :47-166; allocates activation buffers for

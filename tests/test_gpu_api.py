@@ -154,6 +154,32 @@ def test_head_forward_takes_backbone_features_like_the_reference(model, frames2)
         acr.head_forward(torch.zeros(2, 31, 128, 128).cuda())
 
 
+def test_head_forward_on_the_large_batch_lowering(synth_sd, frames2):
+    """contexts built for batches >= 16 write the backbone map as the SECOND output of an ACRMI_CONV_DUAL
+    convolution (aux_buf), not through an op's out_buf - acrmi_heads / acrmi_backbone_channels must find that writer too.
+    Same checks as the small-batch test on a max_batch = 16 engine (the lowering bench.py times)."""
+    acr = pkg('acr.model').ACR(device=0, max_batch=16).eval()
+    acr.load_state_dict(synth_sd)
+    eng = acr.engine(2)
+    L = pkg('_lib')
+    info = eng.program['op_info']
+    assert any(i.get('kernel') == 'conv_wino24b_kernel' for i in info), 'not the large-batch lowering'
+    assert L.lib().acrmi_backbone_channels(eng.ctx) == 32
+    x = torch.from_numpy(frames2).cuda()
+    whole = {k: v.clone() for k, v in acr.head_forward(x).items()}
+    feats = acr.backbone(x)
+    assert feats.shape == (2, 32, 128, 128)
+    hl = eng.program['heads']
+    for si in range(2):
+        eng.buffer(hl.center_buf[si], 2).fill_(float('nan'))
+        eng.buffer(hl.params_buf[si], 2).fill_(float('nan'))
+    eng.buffer(hl.backbone_buf, 2)[..., :32].fill_(float('nan'))
+    heads = acr.head_forward(feats)
+    torch.cuda.synchronize()
+    for k in whole:
+        assert torch.equal(heads[k], whole[k]), k
+
+
 def test_main_acr_results_dict(synth_sd, mano_tables, frames2):
     """acr.main.ACR(...)(bgr_frame, path) -> {path: [float16 hand dicts]} (acr/main.py:92-123, acr/utils.py:1226-1271)."""
     g = golden('e2e_batch1.npz')
