@@ -14,7 +14,8 @@ CONV_SPLITK = 16       # acrmi_op.flags of a CONV: ACRMI_CONV_SPLITK
 CONV_DUAL = 32         # acrmi_op.flags of a CONV: ACRMI_CONV_DUAL (second output = the full-resolution HR fuse sum)
 OPT_POINT_HEADS, OPT_LANES, OPT_CENTER_IDX, OPT_TEMPORAL, OPT_CONF_THRESH, OPT_SMOOTH_COEFF, OPT_MANO_FP16 = 1, 2, 3, 4, 5, 6, 7
 OPT_LANE_PLAN = 8
-VERSION = 302
+OPT_BATCH_PRIOR = 9
+VERSION = 303
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SLOT = 176
 SLOT_FLAG, SLOT_FLATIND, SLOT_SCORE, SLOT_CAM, SLOT_POSES, SLOT_BETAS, SLOT_PARAMS = 0, 1, 2, 3, 6, 54, 64
@@ -38,6 +39,10 @@ class Op(C.Structure):
                 ('flags', C.c_int32), ('mode', C.c_int32)]
 
 
+class Frame(C.Structure):      # acrmi_frame
+    _fields_ = [('bgr_dev', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32)]
+
+
 class HeadLayout(C.Structure):
     _fields_ = [('center_buf', C.c_int32 * 2), ('params_buf', C.c_int32 * 2), ('prior_buf', C.c_int32 * 2),
                 ('segm_buf', C.c_int32), ('backbone_buf', C.c_int32)]
@@ -51,7 +56,7 @@ EXPORTS = ['acrmi_version', 'acrmi_last_error', 'acrmi_create', 'acrmi_destroy',
            'acrmi_comm_unique_id', 'acrmi_comm_init', 'acrmi_comm_destroy', 'acrmi_allgather', 'acrmi_parebias',
            'acrmi_buffer_dtype', 'acrmi_conv2d_h16', 'acrmi_conv2d_splitk', 'acrmi_conv2d_splitk_workspace',
            'acrmi_decode_gated', 'acrmi_decode_maps_gated', 'acrmi_share_weights', 'acrmi_mano_rotmat', 'acrmi_heads',
-           'acrmi_backbone_channels', 'acrmi_check_range']
+           'acrmi_backbone_channels', 'acrmi_check_range', 'acrmi_prior_gate', 'acrmi_preprocess_frames']
 
 _lib = None
 
@@ -103,6 +108,8 @@ def lib():
     L.acrmi_heads.argtypes = [vp, f32p, i32, vp]
     L.acrmi_backbone_channels.argtypes = [vp]
     L.acrmi_check_range.argtypes = [vp, vp]
+    L.acrmi_prior_gate.argtypes = [vp, f32p, i32, vp, vp]
+    L.acrmi_preprocess_frames.argtypes = [C.POINTER(Frame), i32, vp, vp, vp]
     L.acrmi_forward.argtypes = [vp, u8p, i32, f32p, f32p, f32p, f32p, f32p, f32p, f32p, vp]
     L.acrmi_conv2d.argtypes = [f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, i32, f32p, i32, i32, f32p, i32, i32,
                                i32, i32, i32, i32, i32, i32, vp]

@@ -95,13 +95,17 @@ class ACR(object):
     __call__ = forward
 
     @torch.no_grad()
-    def forward_batch(self, rgb_u8_frames, paths, offsets=None, point_heads=True):
+    def forward_batch(self, rgb_u8_frames, paths, offsets=None, point_heads=True, batch_semantics=None):
         """Batched throughput path: uint8 [B,512,512,3] RGB (already pre-processed) -> per-image results.
         One fused call (backbone, heads, decode, MANO, projection) + one D2H of the packed results.
         The head maps are not part of these results, so by default the params/cam/prior towers run only at the
         decoded centers (Engine.set_point_heads; same results within fp32 round-off) - point_heads=False runs the
-        dense heads as `forward` does."""
+        dense heads as `forward` does.
+        batch_semantics: 'frame' | 'reference' (None = the model's ResultParser setting, args().batch_semantics): with
+        'reference' the fused call applies the reference's batch-wide prior rules (acr/result_parser.py:42-47,102-145) on
+        the device - decode, acrmi_prior_gate, gated decode - still ONE call (ACRMI_OPT_BATCH_PRIOR)."""
         eng = self.model.engine(rgb_u8_frames.shape[0])
+        semantics = batch_semantics or self.model._result_parser.batch_semantics
         B = rgb_u8_frames.shape[0]
         if offsets is None:
             offsets = torch.tensor([[512., 512, 0, 0, 0, 0, 0, 0, 0, 0]]).repeat(B, 1)
@@ -109,11 +113,13 @@ class ACR(object):
         # frames of the batch = one video stream, in order (smooth_coeff travels with the call: a reloaded checkpoint
         # builds a new context)
         eng.set_temporal(bool(self.temporal_optimization), smooth_coeff=self._args.smooth_coeff)
+        eng.set_batch_semantics(semantics)
         try:
             out = eng.forward(rgb_u8_frames, offsets=offsets, project=True)
         finally:
             eng.set_point_heads(False)
             eng.set_temporal(False)
+            eng.set_batch_semantics('frame')
         eng.check_range()      # 'fp16x3' only: an activation outside the f16 range is an error, not an empty result
         # cam_trans for every slot (acr/utils.py:399-412): the device least-squares kernel on [B*2] hands
         from .. import ops
@@ -142,8 +148,8 @@ class ACR(object):
 
 
 def _forward_raw_batch(self, bgr_frames_dev, paths):
-    """BASELINE.json config 4: raw BGR uint8 frames [n,H,W,3] resident in HBM (e.g. 1080p video) -> per-image
-    results.  Pre-processing (white square pad + bicubic resize to 512) runs on the GPU (ops.preprocess),
+    """BASELINE.json config 4: raw BGR uint8 frames [n,H,W,3] resident in HBM (e.g. 1080p video) - or a LIST of device frames
+    [H_i,W_i,3] of different sizes (a folder of images, acr/main.py:144-205) - -> per-image results.  Pre-processing (white square pad + bicubic resize to 512) runs on the GPU (ops.preprocess),
     then the fused path; `offsets` carry the pad geometry so pj2d_org lands in original-frame pixels."""
     from .utils import img_preprocess_gpu
     meta = img_preprocess_gpu(bgr_frames_dev, paths)

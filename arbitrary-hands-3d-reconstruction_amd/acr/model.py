@@ -135,11 +135,14 @@ class ACR(object):
         B = eng.backbone_heads(img.contiguous())
         outputs = eng.head_maps(B) if cfg.get('return_maps', True) else {}
         outputs['slots'] = eng.decode(B)
-        eng.check_range()      # 'fp16x3' only: an activation outside the f16 range is an error, not a NaN / empty result
         if self._result_parser.batch_semantics == 'reference' and B > 1:
-            # the reference's batch-wide prior rules (acr/result_parser.py:42-47,131): decided on the host from the first
-            # decode's flags / centers, applied by a second decode (result_parser.reference_prior_gate)
-            outputs['slots'] = eng.decode(B, prior_gate=reference_prior_gate(outputs['slots'], self._result_parser.map_size))
+            # the reference's batch-wide prior rules (acr/result_parser.py:42-47,131): decided ON THE DEVICE from the first
+            # decode's flags / centers (acrmi_prior_gate; result_parser.reference_prior_gate is the host statement of the same
+            # rules, kept for the tests), applied by a second decode - no host round trip between the two
+            outputs['slots'] = eng.decode(B, prior_gate=eng.prior_gate(outputs['slots']))
+        # 'fp16x3' only: an activation outside the f16 range is an error, not a NaN / empty result.  Checked once, behind
+        # everything this call queued (it synchronizes the stream: in front of the second decode it serialized the path)
+        eng.check_range()
         if 'batch_ids' not in meta_data:
             meta_data['batch_ids'] = torch.arange(B)
         outputs.update(rows_from_slots(outputs['slots'], meta_data, self._result_parser.map_size))

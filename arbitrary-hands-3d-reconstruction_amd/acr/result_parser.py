@@ -126,7 +126,7 @@ class ResultParser(object):
                                                prior_gate=gate)
             slots = dec(None)
             if self.batch_semantics == 'reference' and slots.shape[0] > 1:
-                slots = dec(reference_prior_gate(slots, self.map_size))
+                slots = dec(ops.prior_gate(slots))       # acrmi_prior_gate: the batch-wide rules on the device
             outputs['slots'] = slots
         outputs.update(rows_from_slots(slots, meta_data, self.map_size))
         return outputs, meta_data

@@ -82,11 +82,15 @@ def img_preprocess(image, imgpath=None, input_size=512, single_img_input=False, 
 
 
 def img_preprocess_gpu(bgr_frames, imgpaths=None):
-    """Batched device pre-processing: uint8 BGR frames [n,H,W,3] already in HBM ->
+    """Batched device pre-processing: uint8 BGR frames [n,H,W,3] already in HBM - or a list of frames
+    [H_i,W_i,3] of different sizes (acrmi_preprocess_frames) ->
     {'image': uint8 RGB [n,512,512,3] (device), 'offsets': [n,10], 'batch_ids': [n]}: one HIP kernel, no host
     round trip."""
     from .. import ops
-    img, offsets = ops.preprocess(bgr_frames)
+    if isinstance(bgr_frames, (list, tuple)):        # frames of different sizes (folder mode): per-frame geometry, one call
+        img, offsets = ops.preprocess_frames(bgr_frames)
+    else:
+        img, offsets = ops.preprocess(bgr_frames)
     data = {'image': img, 'offsets': offsets, 'data_set': 'internet', 'batch_ids': torch.arange(img.shape[0])}
     if imgpaths is not None:
         data['imgpath'] = list(imgpaths)

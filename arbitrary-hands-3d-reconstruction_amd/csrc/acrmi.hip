@@ -213,6 +213,10 @@ int acrmi_set_option(acrmi_ctx* c, int option, int value) {
     c->mano_f16 = value != 0;
     return ACRMI_OK;
   }
+  if (option == ACRMI_OPT_BATCH_PRIOR) {
+    c->batch_prior = value != 0;
+    return ACRMI_OK;
+  }
   return fail(c, ACRMI_EINVAL, "acrmi_set_option: unknown option %d", option);
 }
 
@@ -327,6 +331,17 @@ int acrmi_decode_gated(acrmi_ctx* c, int B, const int32_t* prior_gate, float* sl
   return r;
 }
 
+int acrmi_prior_gate(acrmi_ctx* c, const float* slots, int B, int32_t* gate, void* stream) {
+  if (!slots || !gate || B <= 0) return fail(c, ACRMI_EINVAL, "acrmi_prior_gate: bad arguments");
+  if (c) {
+    ON_DEVICE(c);
+    HIPCHK(c, launch_prior_gate(slots, B, gate, (hipStream_t)stream));
+    return ACRMI_OK;
+  }
+  HIPCHK(c, launch_prior_gate(slots, B, gate, (hipStream_t)stream));      // stand-alone (like acrmi_decode_maps): current device
+  return ACRMI_OK;
+}
+
 int acrmi_check_range(acrmi_ctx* c, void* stream) {
   if (!c) return fail(c, ACRMI_EINVAL, "acrmi_check_range: ctx is NULL");
   if (!c->range_flag) return ACRMI_OK;      // no split-f16 convolution in the program: nothing can overflow
@@ -438,6 +453,12 @@ static int forward_tail(acrmi_ctx* c, int B, const float* offsets, float* slots,
                         float* verts_camed, float* pj2d, float* pj2d_org, hipStream_t stream) {
   int r = acrmi_decode(c, B, slots, stream);
   if (r) return r;
+  if (c->batch_prior && B > 1) {
+    // the reference's batch-wide prior rules (acr/result_parser.py:42-47, 102-145), all on the device: the first decode's flags
+    // and centers -> one decision per frame -> a second decode that applies it (the decode is ~40 us per 64 frames)
+    HIPCHK(c, launch_prior_gate(slots, B, c->gate_buf, stream));
+    if ((r = acrmi_decode_gated(c, B, c->gate_buf, slots, stream))) return r;
+  }
   if (c->temporal && (r = acrmi_smooth(c, slots, B, stream))) return r;   // acr/main.py:69-83, before MANO
   ManoArgs m{};
   m.t[0] = c->mano[0]; m.t[1] = c->mano[1];

@@ -51,6 +51,8 @@ struct acrmi_ctx {
   float* att_ws = nullptr;      // attention-pool workspace
   size_t att_ws_floats = 0;
   int* picks = nullptr;         // point heads: decoded centers per frame [max_batch,4]
+  int* gate_buf = nullptr;      // ACRMI_OPT_BATCH_PRIOR: the batch-wide prior decision per frame [max_batch] (acrmi_prior_gate)
+  bool batch_prior = false;     // ACRMI_OPT_BATCH_PRIOR: acrmi_forward applies the reference's batch-wide prior rules at B > 1
   unsigned* range_flag = nullptr;   // 'fp16x3' programs (algo 6): set by conv_x3 / conv_x3p when an activation left the f16 range
                                     // (acrmi_check_range reads and clears it; acrmi_decode poisons the slots while it is set)
   bool point_heads = false;     // ACRMI_OPT_POINT_HEADS

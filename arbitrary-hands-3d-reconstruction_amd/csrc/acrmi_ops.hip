@@ -177,6 +177,34 @@ int acrmi_preprocess(const uint8_t* bgr_dev, int n, int H, int W, uint8_t* out_r
   return e == hipSuccess ? ACRMI_OK : fail(nullptr, ACRMI_EHIP, "preprocess: %s", hipGetErrorString(e));
 }
 
+int acrmi_preprocess_frames(const acrmi_frame* frames_host, int n, uint8_t* out_rgb_dev, float* offsets_host, void* stream) {
+  if (!frames_host || !out_rgb_dev || n <= 0) return fail(nullptr, ACRMI_EINVAL, "acrmi_preprocess_frames: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (!frames_host[i].bgr_dev || frames_host[i].H <= 0 || frames_host[i].W <= 0)
+      return fail(nullptr, ACRMI_EINVAL, "acrmi_preprocess_frames: frame %d: null pointer or empty size (%d x %d)", i,
+                  frames_host[i].H, frames_host[i].W);
+  for (int i0 = 0; i0 < n; i0 += PRE_FRAMES_PER_LAUNCH) {
+    const int m = n - i0 < PRE_FRAMES_PER_LAUNCH ? n - i0 : PRE_FRAMES_PER_LAUNCH;
+    PreBatch pb{};
+    for (int i = 0; i < m; ++i) {
+      const acrmi_frame& fr = frames_host[i0 + i];
+      pb.f[i].bgr = fr.bgr_dev; pb.f[i].H = fr.H; pb.f[i].W = fr.W;
+      if (offsets_host) {     // the reference's `offsets` row of this image (acr/utils.py:1276-1313)
+        const int H = fr.H, W = fr.W, S = H > W ? H : W;
+        int top = 0, right = 0, bottom = 0, left = 0;
+        if (W < H) { const int d = H - W; right = (d + 1) / 2; left = d / 2; }
+        else if (H < W) { const int d = W - H; top = d / 2; bottom = (d + 1) / 2; }
+        float* o = offsets_host + (size_t)(i0 + i) * 10;
+        o[0] = (float)S; o[1] = (float)S; o[2] = o[3] = o[4] = o[5] = 0.f;
+        o[6] = (float)top; o[7] = (float)right; o[8] = (float)bottom; o[9] = (float)left;
+      }
+    }
+    hipError_t e = launch_preprocess_frames(pb, m, 512, out_rgb_dev + (size_t)i0 * 512 * 512 * 3, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, ACRMI_EHIP, "preprocess_frames: %s", hipGetErrorString(e));
+  }
+  return ACRMI_OK;
+}
+
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream) {
   if (!img || !out || n_pixels <= 0) return fail(nullptr, ACRMI_EINVAL, "acrmi_u8norm: bad arguments");
   hipError_t e = launch_u8norm(img, n_pixels, out, (hipStream_t)stream);

@@ -20,6 +20,8 @@ void free_program(acrmi_ctx* c) {
   c->att_ws = nullptr;
   if (c->picks) (void)hipFree(c->picks);
   c->picks = nullptr;
+  if (c->gate_buf) (void)hipFree(c->gate_buf);
+  c->gate_buf = nullptr;
   if (c->range_flag) (void)hipFree(c->range_flag);
   c->range_flag = nullptr;
   c->have_program = false;
@@ -565,6 +567,7 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
   c->att_ws_floats = attpool_ws_floats(max_batch, 320);
   HIPCHK(c, hipMalloc(&c->att_ws, c->att_ws_floats * sizeof(float)));
   HIPCHK(c, hipMalloc(&c->picks, (size_t)max_batch * 4 * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->gate_buf, (size_t)max_batch * sizeof(int)));
   for (int i = 0; i < n_ops; ++i)
     if (ops[i].kind == ACRMI_OP_CONV && (ops[i].flags & 7) == 6 && !c->range_flag) {
       HIPCHK(c, hipMalloc(&c->range_flag, sizeof(unsigned)));

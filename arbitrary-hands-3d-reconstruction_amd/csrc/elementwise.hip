@@ -387,6 +387,62 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
   }
 }
 
+// The same arithmetic with PER-FRAME geometry (acr/utils.py:1315-1337 is per image; folder mode, acr/main.py:144-205, mixes
+// sizes): up to PRE_FRAMES_PER_LAUNCH frames per launch, their {pointer, H, W} by value in the kernel arguments (no device
+// table to allocate or upload).  256 consecutive output pixels never straddle a frame (512 * 512 % 256 == 0).
+__global__ __launch_bounds__(256) void preprocess_frames_kernel(const PreBatch pb, int n, int out_size, uint8_t* __restrict__ out) {
+  const long total = (long)n * out_size * out_size;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = i % out_size;
+    const int oy = (i / out_size) % out_size;
+    const int f = i / ((long)out_size * out_size);
+    const int H = pb.f[f].H, W = pb.f[f].W;
+    // imgaug compute_paddings_to_reach_aspect_ratio(shape, 1.0): pad the shorter side, the extra pixel bottom / right
+    const int S = H > W ? H : W;
+    const int pad_top = H < W ? (W - H) / 2 : 0, pad_left = W < H ? (H - W) / 2 : 0;
+    const double scale = (double)S / (double)out_size;
+    int sy, sx, cy[4], cx[4];
+    cv_cubic_taps(oy, scale, sy, cy);
+    cv_cubic_taps(ox, scale, sx, cx);
+    int acc[3] = {0, 0, 0};
+    const uint8_t* src = pb.f[f].bgr;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = sy - 1 + a;
+      yy = yy < 0 ? 0 : (yy >= S ? S - 1 : yy);
+      const int iy = yy - pad_top;
+      int row[3] = {0, 0, 0};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        int xx = sx - 1 + b;
+        xx = xx < 0 ? 0 : (xx >= S ? S - 1 : xx);
+        const int ix = xx - pad_left;
+        int v0 = 255, v1 = 255, v2 = 255;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          const uint8_t* p = src + ((size_t)iy * W + ix) * 3;
+          v0 = p[2]; v1 = p[1]; v2 = p[0];
+        }
+        row[0] += cx[b] * v0; row[1] += cx[b] * v1; row[2] += cx[b] * v2;
+      }
+      acc[0] += cy[a] * row[0]; acc[1] += cy[a] * row[1]; acc[2] += cy[a] * row[2];
+    }
+    uint8_t* o = out + (size_t)i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int r = (acc[c] + (1 << 21)) >> 22;
+      o[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+  }
+}
+
+hipError_t launch_preprocess_frames(const PreBatch& pb, int n, int out_size, uint8_t* out, hipStream_t s) {
+  const long total = (long)n * out_size * out_size;
+  long g = (total + 255) / 256;
+  if (g > 256L * 32) g = 256L * 32;
+  hipLaunchKernelGGL(preprocess_frames_kernel, dim3((unsigned)g), dim3(256), 0, s, pb, n, out_size, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int pad_top, int pad_left, int out_size,
                              uint8_t* out, hipStream_t s) {
   const long total = (long)n * out_size * out_size;

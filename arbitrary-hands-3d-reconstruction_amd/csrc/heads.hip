@@ -447,6 +447,46 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// acr/result_parser.py:85-145 at batch > 1, the part that looks across frames: l_ids / r_ids = the frames whose left / right
+// center passed the threshold, ascending; a side without any hit in the whole batch carries a placeholder row whose flag is
+// False, and :131 wants every flag set - no prior anywhere; determine_coeff (:42-47) compares l_cyxs[0] with r_cyxs[0] - the
+// FIRST left-detected frame's left center and the FIRST right-detected frame's right center, not necessarily one frame - and
+// more than 32 map pixels apart zeroes both coefficients for the whole batch; otherwise the prior is added in exactly the
+// frames that have both hands (all_hand_valid_batch_ids, :128).  A reduction over <= 2 B flags: one workgroup of 256 threads.
+__global__ __launch_bounds__(256) void prior_gate_kernel(const float* __restrict__ slots, int B, int* __restrict__ gate) {
+  __shared__ int first[2][4];
+  const int tid = threadIdx.x;
+  int f0 = 0x7fffffff, f1 = 0x7fffffff;      // lowest frame index with a left / right detection seen by this thread
+  for (int b = tid; b < B; b += 256) {
+    const float* sl = slots + (size_t)b * 2 * ACRMI_SLOT;
+    if (sl[ACRMI_SLOT_FLAG] > 0.5f) f0 = min(f0, b);
+    if (sl[ACRMI_SLOT + ACRMI_SLOT_FLAG] > 0.5f) f1 = min(f1, b);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    f0 = min(f0, __shfl_down(f0, off, 64));
+    f1 = min(f1, __shfl_down(f1, off, 64));
+  }
+  if ((tid & 63) == 0) { first[0][tid >> 6] = f0; first[1][tid >> 6] = f1; }
+  __syncthreads();
+  f0 = min(min(first[0][0], first[0][1]), min(first[0][2], first[0][3]));
+  f1 = min(min(first[1][0], first[1][1]), min(first[1][2], first[1][3]));
+  int on = 0;
+  if (f0 < B && f1 < B) {
+    const int fl = (int)slots[((size_t)f0 * 2 + 0) * ACRMI_SLOT + ACRMI_SLOT_FLATIND];
+    const int fr = (int)slots[((size_t)f1 * 2 + 1) * ACRMI_SLOT + ACRMI_SLOT_FLATIND];
+    const float dy = (float)(fl >> 6) - (float)(fr >> 6), dx = (float)(fl & 63) - (float)(fr & 63);
+    on = !(sqrtf(dy * dy + dx * dx) > 32.f);
+  }
+  for (int b = tid; b < B; b += 256) {
+    const float* sl = slots + (size_t)b * 2 * ACRMI_SLOT;
+    gate[b] = (on && sl[ACRMI_SLOT_FLAG] > 0.5f && sl[ACRMI_SLOT + ACRMI_SLOT_FLAG] > 0.5f) ? 1 : 0;
+  }
+}
+hipError_t launch_prior_gate(const float* slots, int B, int* gate, hipStream_t s) {
+  hipLaunchKernelGGL(prior_gate_kernel, dim3(1), dim3(256), 0, s, slots, B, gate);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Temporal smoothing between decode and MANO (acr/main.py:69-83, acr/utils.py:1466-1527): one One-Euro filter set
 // per hand type (poses[3:48], betas, and the global orientation as a 3x3 rotation matrix), applied to the frames of

@@ -124,6 +124,16 @@ struct FuseArgs {
 hipError_t launch_fuse_sum(const FuseArgs& a, hipStream_t s);
 hipError_t launch_preprocess(const uint8_t* bgr, int n, int H, int W, int S, int pad_top, int pad_left, int out_size,
                              uint8_t* out, hipStream_t s);
+// frames of DIFFERENT sizes in one launch (acrmi_preprocess_frames): geometry by value, PRE_FRAMES_PER_LAUNCH per launch
+constexpr int PRE_FRAMES_PER_LAUNCH = 128;
+struct PreFrame {
+  const uint8_t* bgr;
+  int H, W;
+};
+struct PreBatch {
+  PreFrame f[PRE_FRAMES_PER_LAUNCH];
+};
+hipError_t launch_preprocess_frames(const PreBatch& pb, int n, int out_size, uint8_t* out, hipStream_t s);
 hipError_t launch_pow11(float* buf, long n_pixels, int cs, int ch, hipStream_t s);
 // fp32 NCHW [B,C,H,W] -> channels [coff, coff + C) of an NHWC buffer with channel stride cs (acrmi_heads: backbone features a
 // caller hands to head_forward, acr/model.py:47-53)
@@ -174,6 +184,10 @@ struct DecodeArgs {
                          // has applied the reference's batch-wide rules, acr/result_parser.py:42-47,131)
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+// The reference's BATCH-WIDE prior decision (acr/result_parser.py:42-47, 102-145) from a first decode's slots [B,2,ACRMI_SLOT]:
+// gate[b] = 1 when frame b has both hands AND the batch has a left and a right detection AND the left center of the FIRST
+// left-detected frame and the right center of the FIRST right-detected frame are <= 32 map pixels apart; else 0.  One workgroup.
+hipError_t launch_prior_gate(const float* slots, int B, int* gate, hipStream_t s);
 
 // One-Euro smoothing of the decoded (poses, betas) of one video stream, frames in order (acr/utils.py:1466-1527)
 struct SmoothArgs {

@@ -34,6 +34,7 @@ class Engine(object):
         self.center_idx = 9
         self.temporal = False
         self.mano_fp16 = False
+        self.batch_semantics = 'frame'
         self.smooth_coeff = None          # None = the library default (4.0)
         self.comm_ranks = 0
         self._mano_tables = {}
@@ -199,6 +200,24 @@ class Engine(object):
         _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_MANO_FP16, int(bool(on))), self.ctx)
         self.mano_fp16 = bool(on)
 
+    def set_batch_semantics(self, mode):
+        """ACRMI_OPT_BATCH_PRIOR: 'frame' (default: every frame decides its cross-hand prior like a batch of one) or
+        'reference' (`forward` applies the reference's batch-wide rules at B > 1, acr/result_parser.py:42-47,102-145:
+        decode -> acrmi_prior_gate -> gated decode on the device, one call)."""
+        if mode not in ('frame', 'reference'):
+            raise ValueError("batch_semantics %r: 'frame' or 'reference'" % (mode,))
+        _lib.check(self.L.acrmi_set_option(self.ctx, _lib.OPT_BATCH_PRIOR, int(mode == 'reference')), self.ctx)
+        self.batch_semantics = mode
+
+    def prior_gate(self, slots):
+        """acrmi_prior_gate: slots [B,2,176] of a first decode -> int32 [B] for decode(prior_gate=...), on the device (no
+        host round trip): the reference's batch-wide prior decision (acr/result_parser.py:42-47,102-145)."""
+        if not slots.is_cuda or slots.dtype != torch.float32 or not slots.is_contiguous():
+            raise ValueError('slots must be a contiguous float32 device tensor')
+        gate = torch.empty(slots.shape[0], dtype=torch.int32, device=slots.device)
+        _lib.check(self.L.acrmi_prior_gate(self.ctx, _ptr(slots), slots.shape[0], _ptr(gate), _stream(self.device)), self.ctx)
+        return gate
+
     def smooth(self, slots):
         """One-Euro smoothing of slots [B,2,176] in place (acr/utils.py:1466-1527), state resident in the context."""
         if not slots.is_cuda or slots.dtype != torch.float32 or not slots.is_contiguous():
@@ -251,6 +270,7 @@ class Engine(object):
             self.set_lanes(other.lanes)
         self.set_temporal(other.temporal, smooth_coeff=other.smooth_coeff)
         self.set_mano_fp16(other.mano_fp16)
+        self.set_batch_semantics(getattr(other, 'batch_semantics', 'frame'))
 
     def load_mano_side(self, name, t):
         """One side's tables (mano/manolayer.py:61-102 buffers) -> HBM, blend-shape tables transposed."""

@@ -185,6 +185,29 @@ def preprocess(bgr_frames):
     return out, torch.from_numpy(offsets)
 
 
+def preprocess_frames(bgr_frames):
+    """A list of uint8 BGR device frames [H_i,W_i,3] of ANY sizes -> (uint8 RGB [n,512,512,3] device, offsets [n,10] host) in
+    one call (acrmi_preprocess_frames: per-frame geometry in the kernel arguments).  img_preprocess is per image on the
+    reference (acr/utils.py:1315-1337); folder mode mixes sizes (acr/main.py:144-205)."""
+    frames = list(bgr_frames)
+    if not frames:
+        raise ValueError('no frames')
+    _need_cuda(*frames)
+    keep = []
+    arr = (_lib.Frame * len(frames))()
+    for i, f in enumerate(frames):
+        if f.dtype != torch.uint8 or f.dim() != 3 or f.shape[-1] != 3 or f.device != frames[0].device:
+            raise ValueError('frames must be uint8 [H,W,3] BGR tensors on one device')
+        f = f.contiguous()
+        keep.append(f)                     # bound until the call has been queued
+        arr[i].bgr_dev, arr[i].H, arr[i].W = f.data_ptr(), f.shape[0], f.shape[1]
+    n = len(frames)
+    out = torch.empty(n, 512, 512, 3, dtype=torch.uint8, device=frames[0].device)
+    offsets = np.zeros((n, 10), np.float32)
+    _lib.check(_lib.lib().acrmi_preprocess_frames(arr, n, _p(out), offsets.ctypes.data_as(C.c_void_p), _s(out)))
+    return out, torch.from_numpy(offsets)
+
+
 def cam_trans(joints, pj2d, focal_length=600.0, img_size=512.0):
     """joints [n,21,3], pj2d [n,21,2] (device fp32) -> cam_trans [n,3]: the reference's closed-form least squares
     (acr/utils.py:430-472, unit confidences) on the device."""
@@ -280,3 +303,14 @@ def decode_maps(l_center, r_center, l_params, r_params, l_prior, r_prior, conf_t
                                                   l_params.shape[-1], _p(l_prior), _p(r_prior), l_prior.shape[-1], B,
                                                   float(conf_thresh), _p(gate), _p(slots), _s(slots)))
     return slots
+
+
+def prior_gate(slots):
+    """acrmi_prior_gate (stand-alone form): slots [B,2,176] of a first decode -> int32 [B] for decode_maps(prior_gate=...):
+    the reference's batch-wide prior decision (acr/result_parser.py:42-47,102-145), computed on the device."""
+    _need_cuda(slots)
+    if slots.dtype != torch.float32 or not slots.is_contiguous():
+        raise ValueError('slots must be a contiguous float32 device tensor')
+    gate = torch.empty(slots.shape[0], dtype=torch.int32, device=slots.device)
+    _lib.check(_lib.lib().acrmi_prior_gate(None, _p(slots), slots.shape[0], _p(gate), _s(slots)))
+    return gate

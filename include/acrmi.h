@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ACRMI_VERSION 302
+#define ACRMI_VERSION 303
 
 #define ACRMI_OK 0
 #define ACRMI_EINVAL (-1)  /* bad argument / unsupported shape  (reference: ValueError / assert) */
@@ -205,6 +205,13 @@ int acrmi_decode(acrmi_ctx* ctx, int B, float* slots_dev, void* stream);
  * batch is set; :42-47: determine_coeff reads row 0 of each side's list) - acr/result_parser.py ResultParser(batch_semantics=
  * 'reference') decodes once, applies those batch-wide rules to the flags / centers, and decodes again with the gate. */
 int acrmi_decode_gated(acrmi_ctx* ctx, int B, const int32_t* prior_gate_dev, float* slots_dev, void* stream);
+/* acr/result_parser.py:42-47 (determine_coeff) + :102-145 (parse_maps at batch > 1), the rules that look ACROSS frames, on the
+ * device: slots_dev [B,2,ACRMI_SLOT] of a first decode -> gate_dev [B] int32 for acrmi_decode_gated: 1 in the frames that have
+ * both hands, provided the batch holds a left and a right detection at all (:131) and the left center of the first
+ * left-detected frame is <= 32 map pixels from the right center of the first right-detected frame (:42-47, row 0 of each
+ * list); else 0.  acrmi_forward does decode -> this -> gated decode by itself when ACRMI_OPT_BATCH_PRIOR is set.  ctx may be
+ * NULL (stand-alone use next to acrmi_decode_maps_gated: the current device). */
+int acrmi_prior_gate(acrmi_ctx* ctx, const float* slots_dev, int B, int32_t* gate_dev, void* stream);
 /* 'fp16x3' programs (fp32 tensors, operands split into two f16 numbers - conv algo 6): an activation with |x| > 65504 cannot
  * be split (hi = inf).  The split kernels track it per launch at one v_max3 per two values; while the flag is set acrmi_decode /
  * acrmi_forward write every slot as NaN (so the meshes are NaN too: nothing plausible-looking leaves the library).  This call
@@ -302,6 +309,16 @@ int acrmi_conv2d_h16(const void* in, int B, int H, int W, int in_cs, int in_coff
  * [n,10] (may be NULL) receives the reference's `offsets` rows (padded h, padded w, crop trbl = 0, pad trbl). */
 int acrmi_preprocess(const uint8_t* bgr_dev, int n, int H, int W, uint8_t* out_rgb_dev, float* offsets_host,
                      void* stream);
+/* The same for frames of DIFFERENT sizes in one call (img_preprocess is per image, acr/utils.py:1315-1337; folder mode,
+ * acr/main.py:144-205, mixes sizes): frames_host [n] = where each BGR uint8 frame [H,W,3] lives on the device and its size -
+ * frames need not share an allocation.  Same arithmetic, bit for bit; out_rgb_dev [n,512,512,3]; offsets_host [n,10] (may be
+ * NULL) = each image's own `offsets` row.  The geometry travels in the kernel arguments (128 frames per launch): nothing is
+ * allocated or uploaded, the host array may be freed when the call returns. */
+typedef struct acrmi_frame {
+  const uint8_t* bgr_dev;
+  int32_t H, W;
+} acrmi_frame;
+int acrmi_preprocess_frames(const acrmi_frame* frames_host, int n, uint8_t* out_rgb_dev, float* offsets_host, void* stream);
 int acrmi_u8norm(const uint8_t* img, int n_pixels, float* out, void* stream);
 /* ACRMI_OP_STEM stand-alone: img uint8 RGB [B,H,W,3] (H % 16 == 0, W % 128 == 0) -> [relu](conv3x3 stride 2 pad 1 of
  * (x/255*2-1) + bias) into channels out_coff..out_coff+63 of out [B,H/2,W/2,out_cs]; w_packed = packer.pack_stem(w
@@ -353,6 +370,11 @@ int acrmi_parebias(const float* pooled_dev, int C, int part0, const float* lc_w_
  * it can start first; a cross-stream dependency is charged what it costs on MI355X, ~16 us over an in-stream one)
  * instead of by the structure of the graph alone.  Results do not depend on the assignment.  0 = structural only. */
 #define ACRMI_OPT_LANE_PLAN 8
+/* ACRMI_OPT_BATCH_PRIOR (0/1, default 0): 0 = every frame decides its cross-hand prior for itself - how the reference treats a
+ * batch of ONE frame, the only way acr/main.py:126-141 ever calls it; 1 = acrmi_forward applies the reference's BATCH-WIDE
+ * rules at B > 1 (acr/result_parser.py:42-47, 102-145: see acrmi_prior_gate) - decode, acrmi_prior_gate, gated decode, all on
+ * the stream, no host round trip.  What ResultParser(batch_semantics='reference') / forward_batch(batch_semantics=...) set. */
+#define ACRMI_OPT_BATCH_PRIOR 9
 int acrmi_set_option(acrmi_ctx* ctx, int option, int value);
 /* ACRMI_OPT_CONF_THRESH (default 0.35): center score threshold, strict > (args().centermap_conf_thresh,
  * acr/result_parser.py:198-205,241).  ACRMI_OPT_SMOOTH_COEFF (default 4.0): One-Euro mincutoff of the pose filters

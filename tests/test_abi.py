@@ -25,14 +25,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'libacrmi.so does not export %s' % name
     assert sorted(L.EXPORTS) == declared
-    assert lib.acrmi_version() == L.VERSION == 302
-    for name in ('acrmi_allgather', 'acrmi_comm_init', 'acrmi_smooth', 'acrmi_set_option_f', 'acrmi_heads', 'acrmi_mano_rotmat'):      # SURVEY.md 8b list
+    assert lib.acrmi_version() == L.VERSION == 303
+    for name in ('acrmi_allgather', 'acrmi_comm_init', 'acrmi_smooth', 'acrmi_set_option_f', 'acrmi_heads', 'acrmi_mano_rotmat', 'acrmi_prior_gate',
+                 'acrmi_preprocess_frames'):      # SURVEY.md 8b list
         assert name in declared
 
 
 def test_struct_layout_matches_header():
     L = pkg('_lib')
     assert ctypes.sizeof(L.Op) == 168 and L.Op.w_off.offset == 56 and L.Op.w_off2.offset == 136
+    assert ctypes.sizeof(L.Frame) == 16 and L.Frame.H.offset == 8 and L.Frame.W.offset == 12        # acrmi_frame
     assert ctypes.sizeof(L.BufferDesc) == 20 and L.BufferDesc.dtype.offset == 16 and ctypes.sizeof(L.HeadLayout) == 32
     assert (L.DT_F32, L.DT_F16, L.DT_BF16) == (0, 1, 2)
     src = open(os.path.join(ROOT, 'include', 'acrmi.h')).read()
@@ -67,4 +69,9 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert lib.acrmi_allgather(None, None, None, None, 0, None) == L.E_INVAL
     assert lib.acrmi_comm_unique_id(None) == L.E_INVAL
     assert lib.acrmi_comm_init(None, 1, 0, None) == L.E_INVAL
+    assert lib.acrmi_prior_gate(None, None, 2, None, None) == L.E_INVAL
+    assert lib.acrmi_preprocess_frames(None, 1, None, None, None) == L.E_INVAL
+    bad = (L.Frame * 1)()
+    bad[0].H, bad[0].W = 4, 4                                         # a frame without a pointer
+    assert lib.acrmi_preprocess_frames(bad, 1, ctypes.c_void_p(16), None, None) == L.E_INVAL
     assert lib.acrmi_decode_maps(None, None, 4, None, None, 112, None, None, 108, 1, 0.35, None, None) == L.E_INVAL

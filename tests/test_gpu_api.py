@@ -309,6 +309,69 @@ def test_model_forward_at_batch_gt_1_matches_the_reference(name, mano_tables):
     m.engine().close()
 
 
+@pytest.mark.parametrize('B', [1, 2, 3, 64, 300])
+def test_prior_gate_kernel_equals_the_host_statement_of_the_rule(B):
+    """acrmi_prior_gate (the batch-wide prior decision of acr/result_parser.py:42-47,102-145 on the device)
+    == result_parser.reference_prior_gate (the host statement pinned to the real reference's rows by
+    tests/test_host_api.py::test_reference_batch_semantics_host_logic) on random detection states - including batches without
+    any left / any right detection, first detections in different frames, and centers exactly 32 px apart."""
+    rp, ops, L = pkg('acr.result_parser'), pkg('ops'), pkg('_lib')
+    rs = np.random.RandomState(B)
+    for trial in range(12):
+        slots = rs.randn(B, 2, L.SLOT).astype(np.float32)
+        p_on = (0.0, 0.15, 0.5, 0.9)[trial % 4]
+        slots[:, :, L.SLOT_FLAG] = (rs.rand(B, 2) < p_on).astype(np.float32)
+        if trial == 5:
+            slots[:, 0, L.SLOT_FLAG] = 0           # no left hand in the whole batch
+        if trial == 6:
+            slots[:, 1, L.SLOT_FLAG] = 0
+        flat = rs.randint(0, 4096, size=(B, 2))
+        if trial >= 8:                             # distances around the 32 px bound (exactly 32: still a prior)
+            flat[:, 0] = 10 * 64 + 5
+            flat[:, 1] = 10 * 64 + 5 + (32 if trial % 2 == 0 else 33)
+        slots[:, :, L.SLOT_FLATIND] = flat
+        dev = torch.from_numpy(slots).cuda()
+        got = ops.prior_gate(dev).cpu().numpy()
+        want = rp.reference_prior_gate(dev).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg='B %d trial %d' % (B, trial))
+
+
+@pytest.mark.parametrize('name', list(cases.E2E_BATCHES))
+def test_fused_forward_applies_reference_batch_semantics_in_one_call(name, mano_tables):
+    """Engine.forward / acrmi_forward with ACRMI_OPT_BATCH_PRIOR = decode -> acrmi_prior_gate -> gated decode
+    -> MANO inside the ONE fused call.  Slots are bit-equal to the three-call path (decode, host rule, gated decode); the
+    meshes are those of the real reference's batch (tests/golden/e2e_batches.npz); 'frame' mode stays the plain decode."""
+    g = golden('e2e_batches.npz')
+    rp, L = pkg('acr.result_parser'), pkg('_lib')
+    seed, B = cases.E2E_BATCHES[name]
+    eng = pkg('engine').Engine(0)
+    eng.load_state_dict(pkg('synth').make_state_dict(seed=seed), max_batch=B)
+    tables = {k: dict(v) for k, v in mano_tables.items()}
+    tables['left']['shapedirs'] = tables['left']['shapedirs'].copy()
+    tables['left']['shapedirs'][:, 0, :] *= -1          # acr/mano_wrapper.py:35 (MANOWrapper does this itself)
+    eng.load_mano(tables)
+    frames = torch.from_numpy(pkg('synth').make_frames(B, seed=cases.STATE_FRAME_SEED)).cuda()
+    eng.set_batch_semantics('reference')
+    out = eng.forward(frames)
+    torch.cuda.synchronize()
+    first = eng.decode(B)
+    want = eng.decode(B, prior_gate=rp.reference_prior_gate(first))
+    assert torch.equal(out['slots'], want)
+    # the real reference's rows: row i = frame reorganize_idx[i], hand output_hand_type[i]
+    flags = g[name + '_detection_flag']
+    for i, (b, h) in enumerate(zip(g[name + '_reorganize_idx'], g[name + '_output_hand_type'])):
+        if flags[i]:
+            assert out['slots'][b, h, L.SLOT_FLAG].item() > 0.5
+            assert np.abs(out['verts'][b, h].cpu().numpy() - g[name + '_verts'][i]).max() < 1e-4, (name, i)
+    eng.set_batch_semantics('frame')
+    plain = eng.forward(frames)
+    torch.cuda.synchronize()
+    assert torch.equal(plain['slots'], first)
+    with pytest.raises(ValueError):
+        eng.set_batch_semantics('whole-batch')
+    eng.close()
+
+
 def test_cam_trans_kernel_matches_reference_least_squares():
     """§8f-3: acrmi_cam_trans == the reference's closed-form least squares (acr/utils.py:430-472; restated in numpy
     fp64 in oracle/smooth.py and pinned against the reference's cam_trans in test_oracle_pinned)."""
@@ -354,6 +417,40 @@ def test_gpu_preprocess_is_bit_exact_to_the_opencv_restatement():
     dev_img, _ = ops.preprocess(torch.from_numpy(noise).cuda())
     for i in range(2):
         assert torch.equal(dev_img[i].cpu(), torch.from_numpy(opre.img_preprocess(noise[i])[0]))
+
+
+def test_gpu_preprocess_of_mixed_size_frames_in_one_call():
+    """acrmi_preprocess_frames - per-frame geometry, ONE call for a folder of images of different sizes
+    (img_preprocess is per image, acr/utils.py:1315-1337; acr/main.py:144-205 mixes sizes) - bit-exact to oracle/preprocess.py
+    frame by frame, offsets rows included; frames live in separate allocations; > 128 frames take several launches."""
+    from oracle import preprocess as opre
+    ops, u = pkg('ops'), pkg('acr.utils')
+    rs = np.random.RandomState(11)
+    sizes = ((480, 640), (1080, 1920), (333, 517), (512, 512), (700, 301), (64, 48), (301, 700), (2, 3))
+    frames = [_blocky(rs, H, W) if min(H, W) > 8 else rs.randint(0, 256, (H, W, 3)).astype(np.uint8) for H, W in sizes]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    img, off = ops.preprocess_frames(dev)
+    assert img.shape == (len(sizes), 512, 512, 3) and off.shape == (len(sizes), 10)
+    for i, f in enumerate(frames):
+        want_img, want_off = opre.img_preprocess(f)
+        assert torch.equal(img[i].cpu(), torch.from_numpy(want_img)), sizes[i]
+        assert torch.equal(off[i], torch.from_numpy(want_off)), sizes[i]
+    # the equal-size entry point computes the same bytes
+    same, _ = ops.preprocess(dev[0][None])
+    assert torch.equal(same[0], img[0])
+    # 130 small frames: two launches (128 geometry records per launch), every frame its own size
+    many = [rs.randint(0, 256, (20 + i % 7, 31 + i % 5, 3)).astype(np.uint8) for i in range(130)]
+    img2, off2 = ops.preprocess_frames([torch.from_numpy(f).cuda() for f in many])
+    for i in (0, 1, 127, 128, 129):
+        want_img, want_off = opre.img_preprocess(many[i])
+        assert torch.equal(img2[i].cpu(), torch.from_numpy(want_img)), i
+        assert torch.equal(off2[i], torch.from_numpy(want_off)), i
+    meta = u.img_preprocess_gpu(dev[:3], ['a', 'b', 'c'])                 # the acr.utils surface takes the list form
+    assert torch.equal(meta['image'], img[:3]) and meta['imgpath'] == ['a', 'b', 'c']
+    with pytest.raises(ValueError):
+        ops.preprocess_frames([])
+    with pytest.raises(ValueError):
+        ops.preprocess_frames([torch.zeros(4, 4, 4, dtype=torch.uint8).cuda()])
 
 
 def test_magic_jpg_end_to_end_matches_reference(synth_sd, mano_tables):
