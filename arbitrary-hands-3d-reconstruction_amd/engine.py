@@ -16,6 +16,15 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def torch_nccl_group_active():
+    """True when torch.distributed is initialised with the NCCL (= RCCL on ROCm) backend in this process."""
+    try:
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized() and str(dist.get_backend()).lower() == 'nccl')
+    except Exception:      # noqa: BLE001 - no torch.distributed in this build
+        return False
+
+
 class Engine(object):
     def __init__(self, device=0):
         if not torch.cuda.is_available():
@@ -229,8 +238,18 @@ class Engine(object):
         _lib.check(self.L.acrmi_smooth_reset(self.ctx, _stream(self.device)), self.ctx)
 
     # ---- multi-GPU ----------------------------------------------------------------
-    def comm_init(self, n_ranks, rank, unique_id):
-        """acrmi_comm_init: RCCL communicator on this context's device (collective)."""
+    def comm_init(self, n_ranks, rank, unique_id, allow_second_communicator=False):
+        """acrmi_comm_init: RCCL communicator on this context's device (collective).
+        Refused when this process already runs a torch.distributed NCCL (= RCCL) process group: a process that holds TWO RCCL
+        communicators pays +11 ms per batch for a side-stream all-gather next to a running batch (46.8 vs 35.4 ms at world size
+        1, tools/allgather_probe.py) - a host uses ONE of the two transports (the C transport's control
+        plane runs over gloo).  allow_second_communicator=True overrides (correctness is unaffected; tests use it)."""
+        if not allow_second_communicator and torch_nccl_group_active():
+            raise _lib.AcrmiError(
+                'acrmi_comm_init: this process already runs a torch.distributed NCCL (RCCL) process group; a second RCCL '
+                'communicator next to it costs ~11 ms per batch (DESIGN.md section 6).  Use ONE transport: '
+                "ShardedRunner(transport='torch') on the NCCL group, or initialise torch.distributed with backend 'gloo' for the "
+                "control plane of transport='c'.  (allow_second_communicator=True overrides.)")
         uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         _lib.check(self.L.acrmi_comm_init(self.ctx, int(n_ranks), int(rank), uid), self.ctx)
         self.comm_ranks = int(n_ranks)

@@ -72,9 +72,11 @@ def all_gather_results(flat_local, n_local, group=None):
     return split_gathered(gathered, world, n_local)
 
 
-def init_engine_comm(engine, group=None):
+def init_engine_comm(engine, group=None, allow_second_communicator=False):
     """Creates the engine's own RCCL communicator (acrmi_comm_init): rank 0 draws the 128-byte unique id and the
-    existing process group (any backend) carries it to the other ranks - the host's "own means" of include/acrmi.h."""
+    existing process group (any backend) carries it to the other ranks - the host's "own means" of include/acrmi.h.
+    With a torch NCCL group as the carrier the process would hold two RCCL communicators (+11 ms per batch, DESIGN.md
+    section 6): Engine.comm_init refuses unless allow_second_communicator - carry the id over a gloo group instead."""
     import ctypes as C
     from . import _lib
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -85,7 +87,7 @@ def init_engine_comm(engine, group=None):
         box[0] = bytes(uid)
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    engine.comm_init(world, rank, box[0])
+    engine.comm_init(world, rank, box[0], allow_second_communicator=allow_second_communicator)
 
 
 class ShardedRunner(object):
@@ -93,9 +95,10 @@ class ShardedRunner(object):
     local_forward is Engine.forward on a GPU rank; tests substitute a CPU stand-in over gloo.
 
     transport: 'torch' (torch.distributed) or 'c' (acrmi_allgather on `engine`'s communicator); default from
-    ACRMI_GATHER, else 'torch'."""
+    ACRMI_GATHER, else 'torch'.  transport 'c' next to a torch NCCL group is refused (two RCCL communicators in one
+    process: +11 ms per batch) unless allow_second_communicator."""
 
-    def __init__(self, local_forward, device, group=None, engine=None, transport=None):
+    def __init__(self, local_forward, device, group=None, engine=None, transport=None, allow_second_communicator=False):
         self.local_forward = local_forward
         self.device = torch.device(device)
         self.group = group
@@ -107,7 +110,7 @@ class ShardedRunner(object):
             if engine is None:
                 raise ValueError("transport 'c' needs the Engine whose context owns the communicator")
             if not engine.comm_ranks:
-                init_engine_comm(engine, group)
+                init_engine_comm(engine, group, allow_second_communicator=allow_second_communicator)
         self._buf = {}          # n_local -> two (flat, views, gathered) sets
         self._turn = 0
         self._comm_stream = None
@@ -202,6 +205,37 @@ class ShardedRunner(object):
             torch.cuda.current_stream(self.device).wait_event(ticket['event'])
         _, _, gathered = self._set(ticket['n_local'], ticket['turn'])
         return split_gathered(gathered, dist.get_world_size(self.group), ticket['n_local'])
+
+    def time_gather(self, n_local, iters=10):
+        """Milliseconds per all-gather of an n_local-frame shard BY ITSELF on the gather stream (collective: every rank calls
+        it).  Diagnostics for the first multi-GPU runs (bench.py --gpus N reports it next to the per-rank step times): in
+        the step loop the gather is queued behind a batch and hidden by the next one; this is what it costs uncovered."""
+        import time
+        flat, _, gathered = self._set(n_local, 0)
+
+        def one():
+            if self.transport == 'c':
+                self.engine.allgather(flat, gathered, stream=self._comm_stream)
+            else:
+                dist.all_gather_into_tensor(gathered, flat, group=self.group)
+        if self.device.type != 'cuda':
+            one()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                one()
+            return (time.perf_counter() - t0) / iters * 1e3
+        if self._comm_stream is None:
+            self._comm_stream = self._make_comm_stream()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.stream(self._comm_stream):
+            one()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self._comm_stream)
+            for _ in range(iters):
+                one()
+            e1.record(self._comm_stream)
+        torch.cuda.synchronize(self.device)
+        return e0.elapsed_time(e1) / iters
 
     def forward_local(self, frames_local):
         """Weak-scaling entry: every rank already holds its own frames."""

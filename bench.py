@@ -566,6 +566,38 @@ def run_pipelined(n, frames, eng=None, pool=None, runner=None, vsets=None):
     return last
 
 
+def multi_gpu_diagnostics(dist, runner, eng, last, B, world, rank, dt_own, steps, cdev, frames_for_rank=None):
+    """Collective (every rank calls it, behind the timed region).  Returns on rank 0:
+      per_rank_ms_per_step: each rank's own K steps / K, before the closing barrier (a slow GPU / a rank starved of host cores
+        shows here; `ms_per_step` of the line is the MAX over ranks incl. the barrier);
+      gather_ms: one all-gather of a B-frame shard by itself on the gather stream (hidden behind the next batch in the loop);
+      ranks_seen: rank blocks in the last gathered result; ranks_verified: blocks that are BIT-EQUAL to what rank 0 computes
+        for that rank's frames (seed = rank) on its own GPU - a wrong-order or stale gather cannot hide."""
+    synth = pkg('synth')
+    own = torch.tensor([dt_own / steps * 1e3], dtype=torch.float64, device=cdev)
+    per = [torch.zeros_like(own) for _ in range(world)]
+    dist.all_gather(per, own)
+    gather_ms = runner.time_gather(B) if runner is not None else None
+    if rank != 0:
+        return None
+    rows = int(last['slots'].shape[0]) if last is not None else 0
+    verified = 0
+    if last is not None and rows == world * B:
+        for r in range(world):
+            f = frames_for_rank(r) if frames_for_rank else torch.from_numpy(synth.make_frames(B, seed=r, structured=False)).to(eng.device)
+            want = eng.forward(f)
+            if eng.device.type == 'cuda':
+                torch.cuda.synchronize()
+            verified += int(all(torch.equal(last[k][r * B:(r + 1) * B], want[k]) for k in ('slots', 'verts', 'joints')))
+    return {'ranks': world, 'ranks_seen': rows // B if B else 0, 'ranks_verified': verified,
+            'per_rank_ms_per_step': [round(float(p.item()), 3) for p in per],
+            'gather_ms': round(gather_ms, 4) if gather_ms is not None else None,
+            'gather_bytes_per_rank': B * 2 * pkg('parallel').PER_HAND * 4,
+            'transport': runner.transport if runner is not None else None,
+            'note': 'per_rank = each rank\'s own K steps before the closing barrier; gather_ms = the all-gather alone (hidden behind '
+                    'the next batch in the step loop); ranks_verified = gathered blocks bit-equal to rank 0\'s recomputation'}
+
+
 def self_launch(n_gpus, argv):
     """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): re-executes this file under
     torch.distributed.run with one rank per GPU on 127.0.0.1 and a free port (the reference's counterpart is the
@@ -601,6 +633,8 @@ class StandInEngine(object):
         out['joints'].copy_((key[:, :, None, None] - torch.arange(21.)[None, None, :, None] * 1e-3).expand(-1, -1, -1, 3))
 
     def forward(self, frames, out=None):
+        if out is None:
+            out = pkg('parallel').alloc_result(frames.shape[0], self.device)[1]
         self.fill(frames, out)
         return out
 
@@ -628,10 +662,13 @@ def standin_main(args, rank, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     ok = True
+    multi = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        multi = multi_gpu_diagnostics(dist, runner, eng, last, B, world, rank, dt, args.steps, 'cpu',
+                                      frames_for_rank=lambda r: torch.from_numpy(synth.make_frames(B, seed=r, structured=False)))
         # every rank holds every rank's rows, in frame order
         for r in range(world):
             want = parallel.alloc_result(B, eng.device)[1]
@@ -648,7 +685,7 @@ def standin_main(args, rank, world):
                           'config': {'workload': 'stand-in', 'frames_per_gpu': B, 'global_batch': B * world,
                                      'parallelism': 'frame-sharded x%d' % world,
                                      'gather': 'gloo all-gather of result slots per batch' if use_dist else 'none (one rank)'},
-                          'gathered_rows_ok': ok}), flush=True)
+                          'gathered_rows_ok': ok, 'multi_gpu': multi}), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -773,16 +810,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    last = run_steps(args.steps)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's K steps, before it waits for the others
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    multi = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else 'cuda')
+        cdev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        # self-diagnosis of a multi-GPU run (no 8-GPU box was available to any round): every rank's own
+        # step time, the all-gather by itself, and how many ranks' rows arrived - in the line, so that a first hardware SCALE
+        # run that scales badly says where
+        multi = multi_gpu_diagnostics(dist, runner, eng, last, B, world, rank, dt_own, args.steps, cdev)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -866,6 +910,8 @@ def main():
                           'contexts_in_turn': npipe,
                           'gflop_per_frame': GFLOP_PER_FRAME},
                'roofline': None}
+        if multi is not None:
+            out['multi_gpu'] = multi
         guarded(out, 'roofline', roofline_leg)
         prof = prof_box.get('prof', [])
         if isinstance(out.get('roofline'), dict) and 'error' not in out['roofline']:

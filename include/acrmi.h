@@ -396,7 +396,12 @@ int acrmi_smooth_reset(acrmi_ctx* ctx, void* stream);
  * acrmi_comm_unique_id: 128-byte ncclUniqueId, created on rank 0 and handed to every rank by the host's own means;
  * acrmi_comm_init: ncclCommInitRank on the context's device (collective: every rank calls it);
  * acrmi_allgather: ncclAllGather on `stream`; nccl_comm = NULL uses the context's communicator, otherwise a
- * caller-owned ncclComm_t.  RCCL is resolved at run time (dlopen); without it these calls return ACRMI_ESTATE. */
+ * caller-owned ncclComm_t.  RCCL is resolved at run time (dlopen); without it these calls return ACRMI_ESTATE.
+ * ONE RCCL communicator per process: a process that also holds another one (e.g. torch.distributed's NCCL backend) pays ~11 ms
+ * per batch for a side-stream all-gather next to a running batch (measured at world size 1: 46.8 vs 35.4 ms; +0.2 ms with this
+ * library's communicator alone).  The library cannot see other libraries' communicators; the Python host refuses the
+ * combination (Engine.comm_init / parallel.ShardedRunner(transport='c') next to a torch NCCL group raise unless overridden) -
+ * another host either passes ITS communicator as nccl_comm, or runs its control plane over something else (bench.py: gloo). */
 int acrmi_comm_unique_id(void* id128_out);
 int acrmi_comm_init(acrmi_ctx* ctx, int n_ranks, int rank, const void* id128);
 int acrmi_comm_destroy(acrmi_ctx* ctx);

@@ -628,8 +628,13 @@ def test_sharded_runner_over_rccl_world_size_1(synth_sd, mano_tables, frames2):
         x = torch.from_numpy(frames2).cuda()
         want = {k: v.clone() for k, v in eng.forward(x).items()}
         for transport in ('torch', 'c'):
+            if transport == 'c':
+                # the two-communicator hazard is refused by default ...
+                with pytest.raises(pkg('_lib').AcrmiError):
+                    parallel.ShardedRunner(lambda f, views: eng.forward(f, out=views), eng.device, engine=eng, transport='c')
+            # ... and overridable: results are unaffected, only the side-stream gather gets slower
             runner = parallel.ShardedRunner(lambda f, views: eng.forward(f, out=views), eng.device, engine=eng,
-                                            transport=transport)
+                                            transport=transport, allow_second_communicator=True)
             t0 = runner.submit(x)
             t1 = runner.submit(x.flip(0).contiguous())
             r0, r1 = runner.collect(t0), runner.collect(t1)

@@ -257,6 +257,12 @@ def test_bench_gpus2_launches_its_own_ranks():
     assert line['n_gpus'] == 2 and line['steps'] == 3 and line['warmup'] == 1
     assert line['config']['global_batch'] == 4 and line['gathered_rows_ok'] is True
     assert 'STAND-IN' in line['metric']      # can never be mistaken for a measurement
+    # the self-diagnosis of an N > 1 line: every rank's own step time, the gather alone, the ranks whose
+    # rows arrived and were verified against rank 0's recomputation
+    m = line['multi_gpu']
+    assert m['ranks'] == m['ranks_seen'] == m['ranks_verified'] == 2
+    assert len(m['per_rank_ms_per_step']) == 2 and all(v > 0 for v in m['per_rank_ms_per_step'])
+    assert m['gather_ms'] > 0 and m['gather_bytes_per_rank'] == 2 * 2 * (176 + 778 * 3 + 21 * 3) * 4
     # one rank, same entry point
     p1, line1 = _run_bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '2', '--standin'])
     assert p1.returncode == 0 and line1['n_gpus'] == 1

@@ -24,7 +24,7 @@ if os.environ.get('PG') == '1':      # a torch.distributed process group (RCCL) 
 eng = engine.Engine(0)
 uid = (C.c_char * 128)()
 L.check(L.lib().acrmi_comm_unique_id(uid))
-eng.comm_init(1, 0, bytes(uid))
+eng.comm_init(1, 0, bytes(uid), allow_second_communicator=True)      # (PG=1 measures exactly that hazard)
 B = 64
 flat, views = parallel.alloc_result(B, eng.device)
 gathered = torch.empty_like(flat)
