@@ -265,6 +265,30 @@ void build_schedule(acrmi_ctx* c, bool point, bool large) {
   constexpr float SYNC_MS = 0.002f, EVENT_MS = 0.002f;   // (EVENT_MS: what a profiled time includes)
   static const float WAIT_MS = experiment_env("ACRMI_PLAN_WAIT_US") ? 1e-3f * (float)atof(experiment_env("ACRMI_PLAN_WAIT_US")) : 0.016f;
   std::vector<float> fin(planned ? n : 0, 0.f), lane_free(max_lanes, 0.f);
+  static const bool rank_order = !(experiment_env("ACRMI_PLAN_RANK") && atoi(experiment_env("ACRMI_PLAN_RANK")) == 0);
+  if (planned && rank_order) {
+    // Round 6: the ops are PLANNED AND ENQUEUED in order of their upward rank - the measured time of the
+    // longest chain from the op to the end of the program - instead of program order.  Program order walks the four HRNet
+    // branches round-robin, so the greedy earliest-start rule hands whichever lane is free to whatever op comes next and the
+    // critical chain (101 launches of the two low-resolution branches + the head towers) keeps changing lanes, each change a
+    // ~16 us cross-stream wait on the path.  In rank order the critical chain claims its lane first and stays on it; the
+    // side chains fill the other lanes and their cross-lane edges have slack.  Any order that respects S.deps is a valid
+    // enqueue order (every pair of ops that touch one buffer is ordered by an edge).  tools/sched_sim.py (the same cost
+    // model, offline): batch 1 on four lanes 2.20 -> 2.05 ms simulated.
+    std::vector<float> ru(n, 0.f);
+    std::vector<std::vector<int>> succ(n);
+    for (int j : S.order)
+      for (int d : S.deps[j]) succ[d].push_back(j);
+    for (int k = (int)S.order.size() - 1; k >= 0; --k) {
+      const int j = S.order[k];
+      float m = 0.f;
+      for (int s2 : succ[j]) m = std::max(m, ru[s2]);
+      ru[j] = m + std::max(ms[j], 1e-4f);      // (strictly larger than every successor's: the order stays topological)
+    }
+    std::stable_sort(S.order.begin(), S.order.end(), [&](int x, int y) { return ru[x] > ru[y]; });
+  }
+  std::vector<int> pos(n, -1);               // position in the enqueue order (a lane runs its ops in this order)
+  for (int k = 0; k < (int)S.order.size(); ++k) pos[S.order[k]] = k;
   for (int j : S.order) {
     int lane = -1;
     if (planned) {
@@ -298,7 +322,7 @@ void build_schedule(acrmi_ctx* c, bool point, bool large) {
     S.lane[j] = lane;
     std::vector<int> latest(max_lanes, -1);      // waiting for a lane's latest op covers its earlier ones
     for (int d : S.deps[j])
-      if (S.lane[d] != lane && d > latest[S.lane[d]]) latest[S.lane[d]] = d;
+      if (S.lane[d] != lane && (latest[S.lane[d]] < 0 || pos[d] > pos[latest[S.lane[d]]])) latest[S.lane[d]] = d;
     for (int l = 0; l < max_lanes; ++l)
       if (latest[l] >= 0) { S.wait[j].push_back(latest[l]); S.signal[latest[l]] = 1; }
     lane_tail[lane] = j;
