@@ -73,7 +73,7 @@ struct acrmi_ctx {
   size_t split_ws_floats = 0, split_counters = 0;
   ManoTables mano[2]{};
   bool have_mano[2] = {false, false};
-  float* mano_allocs[2][9] = {};   // 6 fp32 tables + 3 f16 copies per side
+  float* mano_allocs[2][11] = {};  // 6 fp32 tables + 3 f16 copies + 2 f16 residual (lo) tables per side
   bool mano_f16 = false;           // ACRMI_OPT_MANO_FP16
   // options the reference reads from its config (acr/config.py): centermap_conf_thresh (acr/result_parser.py:241),
   // align_idx / mano_mesh_root_align (acr/mano_wrapper.py:19-33), -t temporal_optimization + smooth_coeff (acr/main.py:45-47)

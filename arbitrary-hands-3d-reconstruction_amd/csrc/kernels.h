@@ -234,6 +234,11 @@ struct ManoTables {   // device pointers
   const unsigned short* shapedirs_h;
   const unsigned short* posedirs_h;
   const unsigned short* weights_h;
+  // round 6: the two SMALL tables as f16 pairs - lo = f16(x - float(hi)); value = float(hi) + float(lo), ~22 bits - the
+  // skinning weights (a plain-f16 weight near 0.5 is off by 2.4e-4: x a ~0.1 m joint offset = the 6e-5 m of r5's configs[4]) and
+  // the shape blend shapes.  The pose blend table (1.26 of the 1.46 MB per side: what "fp16 MANO LBS" halves) stays plain f16.
+  const unsigned short* shapedirs_l;
+  const unsigned short* weights_l;
 };
 struct ManoArgs {
   ManoTables t[2];

@@ -18,7 +18,9 @@ constexpr int NV = 778, NV3 = 2334;
 
 // H16 = ACRMI_OPT_MANO_FP16 (BASELINE.json configs[4] "fp16 MANO LBS"): the blend-shape tables (shapedirs, posedirs)
 // and the skinning weights are read as f16 copies (0.73 instead of 1.46 MB of L2 traffic per side and hand), every
-// product and sum stays fp32; v_template, the joint regressor and the kinematic chain are untouched.
+// product and sum stays fp32; v_template, the joint regressor and the kinematic chain are untouched.  Round 6: the two
+// small tables (skinning weights 25 KB, shape blend shapes 47 KB) are f16 PAIRS hi + lo (~22 bits) - the plain-f16 skinning
+// weights were all of r5's 6.4e-5 m; the pose blend table, 86 % of the bytes, stays plain f16.
 template <bool H16>
 __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
   // a.slices workgroups per hand (launch_mano): at small batches a hand's 120 us - one CU streaming the 1.26 MB pose-blend
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 10; ++k)
-      s += (H16 ? (float)__builtin_bit_cast(_Float16, T.shapedirs_h[k * NV3 + i]) : T.shapedirs_t[k * NV3 + i]) * sBeta[k];
+      s += (H16 ? (float)__builtin_bit_cast(_Float16, T.shapedirs_h[k * NV3 + i]) + (float)__builtin_bit_cast(_Float16, T.shapedirs_l[k * NV3 + i])
+                : T.shapedirs_t[k * NV3 + i]) * sBeta[k];
     sV[i] = s + T.v_template[i];
   }
   __syncthreads();
@@ -140,9 +143,10 @@ __global__ __launch_bounds__(256) void mano_kernel(const ManoArgs a) {
     for (int e = 0; e < 12; ++e) Tm[e] = 0.f;
     const float* wv = T.weights + v * 16;
     const unsigned short* wh = T.weights_h + v * 16;
+    const unsigned short* wl = T.weights_l + v * 16;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float w = H16 ? (float)__builtin_bit_cast(_Float16, wh[j]) : wv[j];
+      const float w = H16 ? (float)__builtin_bit_cast(_Float16, wh[j]) + (float)__builtin_bit_cast(_Float16, wl[j]) : wv[j];
 #pragma unroll
       for (int e = 0; e < 12; ++e) Tm[e] += sA[j][e] * w;
     }

@@ -460,5 +460,5 @@ def test_mano_fp16_lbs_against_the_reference_vectors(mano_tables):
                         float(np.abs(j.cpu().numpy() - g[key + 'joints']).max()))
         worst['fp16' if fp16 else 'fp32'] = w
     _report('mano_lbs_max_abs_err_m', worst)
-    assert worst['fp32'] < 2e-6 and worst['fp16'] < 1e-4, worst
+    assert worst['fp32'] < 2e-6 and worst['fp16'] < 2e-5, worst      # (r5: 6.4e-5 with plain-f16 skinning weights)
     eng.close()
