@@ -33,7 +33,7 @@ GFLOP_PER_FRAME = 102.1          # BASELINE.md §3 / SURVEY.md §8d (2*MAC, dire
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
 DOMINANT = 'conv_wino24b_kernel + conv_wino3_kernel + conv_wino2_kernel (3x3 stride-1 convolutions: Winograd F(2x4,3x3) / F(2x2,3x3) on fp32 MFMA)'
 MFMA_REDUCTION = {'winograd_f2x2_3x3': 2.25, 'winograd_f2x2_3x3_lds': 2.25, 'winograd_f23x': 1.5, 'winograd_f2x4_3x3': 3.0}   # algorithmic MACs per executed MFMA MAC
-PROFILE_TAGS = ('r05', 'r04', 'r03', 'r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
+PROFILE_TAGS = ('r06', 'r05', 'r04', 'r03', 'r02', 'r01')     # newest committed rocprofv3 summaries first (profiles/, tools/profile_round.sh)
 
 
 def pkg(sub):

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/ on a GPU box (run from the repo root through gpurun):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/profile_round.sh r05'
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/profile_round.sh r06'
 # then copy gpurun_out/<tag>_* into profiles/.  Kernel timing and the PMC passes are separate runs (rocprofv3 --pmc
 # must not be combined with other trace domains on this pool).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
