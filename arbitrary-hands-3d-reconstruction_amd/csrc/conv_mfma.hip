@@ -529,6 +529,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 #include "conv_wino3.inc"
 #include "conv_wino24.inc"
 #include "conv_wino24b.inc"
+#include "conv_wino24c.inc"
 #include "conv_pp2.inc"
 #include "conv_x3.inc"
 #include "conv_x3p.inc"
@@ -575,6 +576,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   if (a.algo == 5) return launch_pp2(a, s);     // 3x3 stride 2, polyphase + F(2,2): weights packed with 4 x 7 taps (conv_pp2.inc)
   if (a.algo == 4)                              // F(2x4,3x3): weights packed with 4x6 taps; four-wave frame where it applies
     {
+      if (wino24c_ok(a)) return launch_wino24c(a, s);      // all 24 positions per wave (round 6; conv_wino24c.inc)
       const int tw = wino24b_ok(a);
       return tw ? launch_wino24b(a, tw, s) : launch_wino24(a, s);
     }

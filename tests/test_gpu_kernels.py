@@ -240,6 +240,51 @@ def test_conv2d_winograd24_four_wave_frame(ops, case):
         assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
 
 
+WINO24C_CASES = [c for c in WINO24B_CASES if c[1] // c[5] >= 64 and (c[2] // c[5]) % 64 == 0 and c[3] % 8 == 0 and c[4] % 32 == 0]
+
+
+@pytest.mark.parametrize('case', WINO24C_CASES, ids=lambda c: 'wino24c_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv2d_winograd24_all_positions_frame(ops, case):
+    """conv_wino24c_kernel (round 6; acrmi_tune cfg 842 - NOT the default, it measured 7 % slower): all 24 Winograd positions
+    of a tile in one wave on v_mfma_f32_16x16x4_f32, transformed fragments exchanged through LDS once per 8-channel step, the
+    whole output transform in registers.  Same products as conv_wino24b_kernel in another summation order: vs an fp64 direct
+    convolution, and within fp32 round-off of the default kernel; channel slices of wider buffers, neighbours untouched."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    L = pkg('_lib').lib()
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 241)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 3, 3, generator=g) / np.sqrt(cin // groups * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 1, 1, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B if res_kind == 1 else 1, cout, H, W), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    outs = []
+    for cfg in (842, -1):
+        dst = torch.full((B, H, W, cout + 16), 7.0, device='cuda')
+        L.acrmi_tune(0, cfg)
+        try:
+            ops.conv2d(xin, w, None if use_fb else b, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo='winograd24',
+                       out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                       frame_bias=None if fb is None else fb.cuda())
+            torch.cuda.synchronize()
+        finally:
+            L.acrmi_tune(0, -1)
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        assert (got.double() - ref).abs().max().item() < 2e-4, cfg
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), cfg
+        outs.append(got)
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5          # another summation order, the same arithmetic
+
+
 PP2_CASES = [
     # (B, Cin, Cout, H, W (INPUT map), groups, relu, residual kind: 0 none / 1 per frame / 2 one map for every frame, frame_bias)
     (2, 32, 64, 32, 64, 1, False, 0, False),       # HRNet fuse chain 32 -> 64: two chunks, 2x2 tiles (all border kinds of a stride-2 map)
