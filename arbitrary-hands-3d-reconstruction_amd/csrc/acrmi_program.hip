@@ -185,6 +185,7 @@ int run_op(acrmi_ctx* c, const acrmi_op& op, const uint8_t* img, int B, hipStrea
       p.prior = ptr(h.prior_buf[side]); p.prior_cs = desc(h.prior_buf[side]).cs;
       p.final_ = ptr(op.out_buf); p.final_cs = desc(op.out_buf).cs;
       p.picks = c->picks; p.side = side; p.B = B; p.thresh = c->conf_thresh;
+      p.prior_when_both = c->batch_prior ? 1 : 0;
       HIPCHK(c, launch_point_heads(p, s));
       return ACRMI_OK;
     }

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void center_pick_kernel(const PointArgs a) {
   pick_centers(a.center, a.center_cs, blockIdx.x, a.thresh, sc, pk);
   if (threadIdx.x == 0) {
     int* o = a.picks + blockIdx.x * 4;
-    o[0] = pk.flat[0]; o[1] = pk.flat[1]; o[2] = pk.prior; o[3] = 0;
+    o[0] = pk.flat[0]; o[1] = pk.flat[1]; o[2] = a.prior_when_both ? (pk.flag[0] && pk.flag[1]) : pk.prior; o[3] = 0;
   }
 }
 

@@ -220,6 +220,9 @@ struct PointArgs {
   int* picks;                              // [B,4] workspace: flat_l, flat_r, prior gate
   int side, B;
   float thresh;                            // centermap_conf_thresh
+  int prior_when_both;                     // ACRMI_OPT_BATCH_PRIOR: evaluate the prior point whenever the frame has BOTH hands - the
+                                           // batch-wide rule (acrmi_prior_gate) may open the gate for a frame whose own centers are
+                                           // more than 32 px apart; the gated decode then decides whether the value is added
 };
 hipError_t launch_point_heads(const PointArgs& a, hipStream_t s);
 

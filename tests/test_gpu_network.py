@@ -204,6 +204,42 @@ def test_point_heads_at_map_borders_and_without_detections(engine, synth_sd):
     _check_point_heads_at(engine, x, [((20, 30), (32, 33)), ((40, 12), (32, 33))])
 
 
+def test_point_heads_under_reference_batch_semantics(engine, synth_sd):
+    """Round 6: with ACRMI_OPT_BATCH_PRIOR the batch-wide rule (acr/result_parser.py:42-47,131) can open the prior gate for a
+    frame whose OWN centers are more than 32 px apart (it looks at the first left- / right-detected frames only).  The point
+    heads must then have evaluated that frame's prior point although its per-frame gate is closed.  Planted centers: frame 0
+    near (decides the batch), frame 1 far: point heads + gated decode == gated decode of the dense maps."""
+    synth, rp = pkg('synth'), pkg('acr.result_parser')
+    x = torch.from_numpy(synth.make_frames(2, seed=3, structured=False)).cuda()
+    hl = engine.program['heads']
+    B = engine.backbone_heads(x)                              # dense maps of both frames
+    spots = [((20, 30), (24, 33)), ((5, 6), (58, 57))]        # frame 1: 73 px apart
+    for b, (l, r) in enumerate(spots):
+        for s, (y, xx) in enumerate((l, r)):
+            cm = engine.buffer(hl.center_buf[s], B, 1)
+            cm[b].fill_(0.0)
+            cm[b, y, xx, 0] = 0.9
+    first = engine.decode(B)
+    gate = engine.prior_gate(first)
+    assert gate.tolist() == [1, 1] and rp.reference_prior_gate(first).tolist() == [1, 1]
+    want = engine.decode(B, prior_gate=gate).clone()
+    per_frame = engine.decode(B).clone()
+    assert (want[1] - per_frame[1]).abs().max().item() > 1e-4          # frame 1: the batch rule adds a prior its own rule would not
+    for s in range(2):
+        engine.buffer(hl.params_buf[s], B).fill_(float('nan'))
+        engine.buffer(hl.prior_buf[s], B).fill_(float('nan'))
+    engine.set_batch_semantics('reference')
+    try:
+        engine.run_point_heads(B)
+        got = engine.decode(B, prior_gate=gate)
+        torch.cuda.synchronize()
+    finally:
+        engine.set_batch_semantics('frame')
+    assert not torch.isnan(got).any()
+    assert (got - want).abs().max().item() < 2e-4                      # the point towers' fp32 round-off against the dense maps
+    engine.forward(x)                                                  # the dense program repairs the poisoned maps
+
+
 def _check_point_heads_at(engine, x, spots):
     """spots: per frame (left (y,x), right (y,x)), <= 32 px apart (the prior path runs): peaks planted in the resident
     center maps, point heads re-run on them and compared with the decode of the dense maps."""
