@@ -723,6 +723,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='HIP streams the independent chains of the program run on (ACRMI_OPT_LANES; 0 = library default, 1 per context with --pipeline >= 2)')
     ap.add_argument('--pipeline', type=int, default=2, help='contexts taking batches in turn on their own streams (engine.EnginePool): the tail of one batch overlaps the head of the next; 1 = one context')
     ap.add_argument('--profile-out', default=None, help='write the per-op HIP-event timings (JSON) here')
+    ap.add_argument('--leg-timeout', type=int, default=900, help='seconds the legs BEHIND the timed region (roofline pass, point heads, cpu_baseline, latency, PMC child, other configs) may take before the line is printed without the unfinished ones (0 = no watchdog)')
     ap.add_argument('--standin', action='store_true', help=argparse.SUPPRESS)     # CPU plumbing run over gloo (tests only)
     args = ap.parse_args()
 
@@ -912,6 +913,23 @@ def main():
                'roofline': None}
         if multi is not None:
             out['multi_gpu'] = multi
+        # Watchdog: a leg behind the timed region that HANGS (a GPU fault inside a library call never returns to Python, so
+        # guarded() cannot catch it) must not cost the measured headline either: after --leg-timeout seconds a daemon thread
+        # prints the line as far as it got - `post_timeout` says so - and ends the process.  Disarmed when the legs are done.
+        import threading
+
+        def _give_up():
+            out['post_timeout'] = ('a measurement leg behind the timed region did not return within %d s; the line holds what '
+                                   'was finished until then' % args.leg_timeout)
+            try:
+                sys.stdout.write(json.dumps(out, default=str) + '\n')
+                sys.stdout.flush()
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(args.leg_timeout, _give_up)
+        watchdog.daemon = True
+        if world == 1 and args.leg_timeout > 0:
+            watchdog.start()
         guarded(out, 'roofline', roofline_leg)
         prof = prof_box.get('prof', [])
         if isinstance(out.get('roofline'), dict) and 'error' not in out['roofline']:
@@ -1024,6 +1042,7 @@ def main():
             guarded(out['other_configs'], 'configs[3] 1080p stream, per-GPU shard (32 frames), host memory -> meshes',
                     lambda: config3_video_stream(sd, tables, args.steps, args.warmup, local_rank))
         pool = state['pool']
+        watchdog.cancel()
         line = json.dumps(out)
     else:
         line = None
