@@ -776,7 +776,8 @@ def main():
     eng.load_state_dict(sd, max_batch=B, precision=args.precision)
     eng.load_mano(tables)
     eng.set_lanes(args.lanes)
-    if use_dist and os.environ.get('ACRMI_GATHER') == 'c':
+    comm_late = os.environ.get('ACRMI_COMM_LATE') == '1'      # (experiment switch: communicator behind the pool's streams)
+    if use_dist and os.environ.get('ACRMI_GATHER') == 'c' and not comm_late:
         # the C-ABI transport's own RCCL communicator is created BEFORE the pool's streams exist: a communicator created
         # later lands its internal stream on a hardware queue one of the contexts already uses (r2: 1367 vs 1553 frames/s)
         parallel.init_engine_comm(eng)
@@ -789,6 +790,8 @@ def main():
         pool.load_state_dict(None, max_batch=B, lanes=args.lanes or 1)
         pool.load_mano(None)
 
+    if use_dist and os.environ.get('ACRMI_GATHER') == 'c' and comm_late:
+        parallel.init_engine_comm(eng)
     vsets = [parallel.alloc_result(B, eng.device)[1] for _ in range(npipe)]
     views = vsets[0]
     runner = None
