@@ -407,3 +407,42 @@ def test_hr_fuse_sums_are_lowered_exactly_once_each(synth_sd, lowering):
         assert [o.term_shift[t] for t in range(o.nterms)] == list(range(1, o.nterms + 1))
     for o, i in sums:
         assert o.relu == 1 and 2 <= o.nterms <= 4
+
+
+def test_rank_order_lane_planning_on_a_round_robin_program():
+    """Round 6 lane planner (csrc/acrmi_program.hip build_schedule; tools/sched_sim.py is its cost model in Python): ops taken in
+    UPWARD-RANK order - the longest remaining chain first - instead of program order.  On a program that walks four
+    independent chains of unequal length round-robin (what HRNet's branches look like in program order) the rank order is a
+    valid topological order, keeps the long chain on one lane and is never slower than the program-order plan in the model."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('sched_sim', os.path.join(ROOT, 'tools', 'sched_sim.py'))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    rs = np.random.RandomState(0)
+    lengths = [40, 12, 12, 6]                                  # links per chain; chain 0 is the critical one
+    ms, deps, chain_of, last = [], [], [], [None] * 4
+    for step in range(max(lengths)):                           # round-robin over the chains, like the lowered HR modules
+        for c in range(4):
+            if step < lengths[c]:
+                deps.append([] if last[c] is None else [last[c]])
+                last[c] = len(ms)
+                ms.append(0.010 + 0.004 * rs.rand())
+                chain_of.append(c)
+    ms.append(0.02)                                            # a join (the heads)
+    deps.append([l for l in last if l is not None])
+    chain_of.append(-1)
+    n, W = len(ms), 0.016
+    ru, succ = sim.upward_rank(ms, deps)
+    order = sorted(range(n), key=lambda j: (-ru[j], j))
+    pos = {j: k for k, j in enumerate(order)}
+    assert all(pos[d] < pos[j] for j in range(n) for d in deps[j])          # a valid enqueue order
+    for L in (2, 4):
+        greedy = sim.plan(list(range(n)), ms, deps, L, W)
+        ranked = sim.plan(order, ms, deps, L, W)
+        mg, _ = sim.simulate(list(range(n)), greedy, ms, deps, L, W)
+        mr, _ = sim.simulate(order, ranked, ms, deps, L, W)
+        assert mr <= mg + 1e-9, (L, mg, mr)
+        crit = [j for j in range(n) if chain_of[j] == 0]
+        assert len({ranked[j] for j in crit}) == 1                          # the critical chain never changes lanes
