@@ -141,8 +141,8 @@ class Engine(object):
         library keeps the times and plans the lanes from them), then every candidate lane count is timed with the
         structural and with the planned assignment - `calls` network passes (acrmi_backbone_heads on zero frames,
         after 2 warm-ups) each - and the fastest is set.  Why: what parallel lanes gain depends on state the library
-        cannot see - ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; the package only
-        sets 8 when it is imported before HIP starts), and lane streams created next to other live streams (torch's
+        cannot see - ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, which this package
+        leaves alone since round 6: more queues make five or more busy streams collapse), and lane streams created next to other live streams (torch's
         pools, RCCL, another context) may share a queue with them: measured 7.5-9.9 ms per batch-1 call with four lanes
         in that state against 3.4 ms with their own queues and 5.0 ms on one stream.  Results do not depend on the
         assignment (same kernels, same order per buffer).  When the winner is what the library picks by itself for this

@@ -34,7 +34,6 @@ def main():
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     import torch.distributed as dist
     torch.cuda.set_device(a.rank)
     if a.transport == 'c':

@@ -2,7 +2,7 @@
 """What a cross-stream dependency costs on this box (GPU only): N tiny kernels in one stream vs the same N kernels
 alternating between two streams with an event record + wait between every pair."""
 import os, time
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # this probe's own setting (two streams only); the package leaves the variable alone since round 6
 import torch
 
 x = torch.zeros(1024, device='cuda')

@@ -2,7 +2,7 @@
 planned) candidate.  ACRMI_PLAN_WAIT_US overrides the planner's cross-stream charge (default 16)."""
 import importlib, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench   # noqa: F401  (sets GPU_MAX_HW_QUEUES before HIP starts)
+import bench   # noqa: F401
 pkg = lambda m: importlib.import_module('arbitrary-hands-3d-reconstruction_amd.' + m)
 synth = pkg('synth')
 eng = pkg('engine').Engine(0)

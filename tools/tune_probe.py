@@ -2,7 +2,7 @@
 """Engine.tune_lanes at batch 1 / 8 with every lane count 1..8: call time per (lanes, planned)."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402  (sets GPU_MAX_HW_QUEUES before HIP starts)
+import bench  # noqa: E402
 pkg = bench.pkg
 synth = pkg('synth')
 eng = pkg('engine').Engine(0)
