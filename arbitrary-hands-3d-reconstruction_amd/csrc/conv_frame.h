@@ -10,6 +10,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));   // data operand of the raw buffer store builtins
 
+// max(x, m) as ONE v_max_f32.  fmaxf() on a value hipcc cannot prove canonical (the result of an asm block, of a buffer
+// load) costs two: v_max_f32 x, x, x first - and beside the fp32 MFMAs every VALU instruction of an epilogue is paid in full
+// (DESIGN.md section 2).  Same result as fmaxf for every non-NaN input; a NaN yields m (fmaxf: the same).
+__device__ __forceinline__ float vmax1(float x, float m) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+  return r;
+}
+__device__ __forceinline__ float vrelu1(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // host-side state shared by the launchers of both translation units (defined in conv_mfma.hip)
 int conv_forced_cfg();                 // acrmi_tune key 0 (-1 = automatic)
 int conv_num_cus();                    // CU count of the current device (after conv_ensure_device_info)

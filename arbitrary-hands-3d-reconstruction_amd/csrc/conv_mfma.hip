@@ -177,7 +177,7 @@ __device__ __forceinline__ void epi_store_vec(const EpiCtx& e, Slot2Pix slot2pix
     f32x4 v = {x0 + b4[0], x1 + b4[1], x2 + b4[2], x3 + b4[3]};
     if (has_res) v += rv[gq];
     if (e.relu) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      v[0] = vrelu1(v[0]); v[1] = vrelu1(v[1]); v[2] = vrelu1(v[2]); v[3] = vrelu1(v[3]);
     }
     bool ok;
     const int pix = slot2pix(slot_base + 8 * gq + 4 * lh + lj, ok);
@@ -210,7 +210,7 @@ __device__ __forceinline__ void epi_store_scalar(const EpiCtx& e, Slot2Pix slot2
   for (int r = 0; r < 16; ++r) {
     float v = acc[r] + bv;
     if (has_res) v += rv[r];
-    if (e.relu) v = fmaxf(v, 0.f);
+    if (e.relu) v = vrelu1(v);
     if (cok && ((okm >> r) & 1u)) e.outb[pix[r] * e.out_cs + co] = v;
   }
 }
