@@ -47,9 +47,12 @@ int acrmi_conv2d(const float* in, int B, int H, int W, int in_cs, int in_coff, i
   if (algo >= 0) algo &= ~ACRMI_CONV_BIAS_MAP;
   if (bias_map && (!res || algo == 3))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: ACRMI_CONV_BIAS_MAP needs res (the map) and an algo other than 3");
-  if (algo != 0 && !((algo >= 1 && algo <= 7) && (ksize == 3 || (algo >= 6 && ksize == 1)) && stride == (algo == 5 ? 2 : 1)))
+  const bool x3s2 = (algo == 6 || algo == 7) && ksize == 3 && stride == 2;      // conv_x3s2.inc
+  if (algo != 0 && !x3s2 && !((algo >= 1 && algo <= 7) && (ksize == 3 || (algo >= 6 && ksize == 1)) && stride == (algo == 5 ? 2 : 1)))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo %d needs a 3x3 stride-%d convolution", algo, algo == 5 ? 2 : 1);
-  if ((algo == 6 || algo == 7) && (cin % 32 || cout % 32 || (ksize == 3 ? ((H % 8 || W % 32) && (H % 16 || W % 16)) : ((H * W) % 256 != 0))))
+  if (x3s2 && (cin % 32 || cout % 32 || H % 16 || W % 64))
+    return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 6 / 7 at stride 2 needs Cin %% 32 = 0, Cout %% 32 = 0, H %% 16 == 0, W %% 64 == 0");
+  if ((algo == 6 || algo == 7) && !x3s2 && (cin % 32 || cout % 32 || (ksize == 3 ? ((H % 8 || W % 32) && (H % 16 || W % 16)) : ((H * W) % 256 != 0))))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 6 / 7 needs Cin %% 32 = 0, Cout %% 32 = 0, H %% 8 == 0, W %% 32 == 0");
   if (algo == 5 && (cin % 16 || cout % 32 || H % 16 || W % 32))
     return fail(nullptr, ACRMI_EINVAL, "acrmi_conv2d: algo 5 needs Cin %% 16 = 0, Cout %% 32 = 0, H %% 16 == 0, W %% 32 == 0");

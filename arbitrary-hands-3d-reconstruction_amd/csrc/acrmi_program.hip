@@ -447,7 +447,8 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       }
       if (op.bias_per_frame && buf_ok(op.aux_buf) && bufs[op.aux_buf].dtype != ACRMI_DT_F32)
         return fail(c, ACRMI_EINVAL, "op %d: the per-frame bias must be fp32", i);
-      if (algo != 0 && !((op.ksize == 3 || (algo >= 6 && op.ksize == 1)) && op.stride == (algo == 5 ? 2 : 1)))
+      if (algo != 0 && !((algo == 6 || algo == 7) && op.ksize == 3 && op.stride == 2) &&
+          !((op.ksize == 3 || (algo >= 6 && op.ksize == 1)) && op.stride == (algo == 5 ? 2 : 1)))
         return fail(c, ACRMI_EINVAL, "op %d: algo %d needs a 3x3 stride-%d convolution", i, algo, algo == 5 ? 2 : 1);
       if (algo == 3 && (op.groups != 1 || op.cin > 32 || op.cout != 32 || op.bias_per_frame || bufs[op.out_buf].h % 8 ||
                         bufs[op.out_buf].w % 16 || op.out_coff % 4 || op.res_coff % 4))
@@ -465,6 +466,9 @@ int acrmi_set_program(acrmi_ctx* c, const acrmi_buffer_desc* bufs, int n_bufs, c
       const long long n_tiles = op.cout <= 32 ? 1 : ((op.cout + 63) / 64) * 2;
       if (algo == 4 && (op.cin < 32 || (op.cin == 32 && (op.cout % 32 || ho % 8 || wo % 32))))      // (Cin = 32: conv_wino24b_kernel only)
         return fail(c, ACRMI_EINVAL, "op %d: algo 4 needs Cin > 32, or Cin = 32 with Cout %% 32 = 0 on a map of 8x32-pixel tiles", i);
+      if ((algo == 6 || algo == 7) && op.stride == 2 &&
+          (op.ksize != 3 || ho % 8 || wo % 32 || bufs[op.in_buf].h != 2 * ho || bufs[op.in_buf].w != 2 * wo || op.nterms > 0))      // (conv_x3s2.inc x3s2_ok)
+        return fail(c, ACRMI_EINVAL, "op %d: algo 6 / 7 at stride 2 needs a 3x3 convolution onto a map of 8x32-pixel tiles, even input size, no extra residual terms", i);
       if ((algo == 6 || algo == 7) && (idt || op.cin % 32 || op.cout % 32 || op.out_coff % 4 || op.res_coff % 4 ||
                                        (op.ksize == 3 ? ((ho % 8 || wo % 32) && (ho % 16 || wo % 16)) : ((ho * wo) % 256 != 0))))      // (conv_x3.inc x3_ok / conv_x3p.inc x3p_ok)
         return fail(c, ACRMI_EINVAL, "op %d: algo 6 / 7 needs fp32 storage, Cin %% 32 = 0, Cout %% 32 = 0, a map of 8x32- or 16x16-pixel tiles (3x3) / of whole 256-pixel items (1x1)", i);

@@ -533,6 +533,7 @@ static hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
 #include "conv_pp2.inc"
 #include "conv_x3.inc"
 #include "conv_x3p.inc"
+#include "conv_x3s2.inc"
 #include "conv_p1.inc"
 
 // Tile selection.  N32: one 32-cout tile per wave (Cout <= 32); N64: two.
@@ -572,6 +573,7 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
   if (a.nxt > 0 && a.algo != 5 && a.algo != 0 && !(a.algo == 3 && a.out2)) return hipErrorInvalidValue;      // extra residual terms: the stride-2 kernels, or conv_wino3's second output
   if (a.out2 && a.algo != 3) return hipErrorInvalidValue;
   if ((a.algo == 6 || a.algo == 7) && a.ks == 1) return launch_x3p(a, a.algo == 7, s);      // ... 1x1 (conv_x3p.inc)
+  if ((a.algo == 6 || a.algo == 7) && a.stride == 2) return launch_x3s2(a, a.algo == 7, s);      // ... 3x3 stride 2 (conv_x3s2.inc)
   if (a.algo == 6 || a.algo == 7) return launch_x3(a, a.algo == 7, s);      // 3x3 stride 1, split f16 / bf16 operands on the 16-bit matrix pipe (conv_x3.inc)
   if (a.algo == 5) return launch_pp2(a, s);     // 3x3 stride 2, polyphase + F(2,2): weights packed with 4 x 7 taps (conv_pp2.inc)
   if (a.algo == 4)                              // F(2x4,3x3): weights packed with 4x6 taps; four-wave frame where it applies
@@ -657,8 +659,8 @@ hipError_t launch_conv(ConvArgs a, hipStream_t s) {
 
 const char* conv_kernel_name(const ConvArgs& a) {
   if (a.dtype != ACRMI_DT_F32) return a.dtype == ACRMI_DT_BF16 ? "conv_direct_mfma_bf16" : "conv_direct_mfma_f16";
-  if (a.algo == 7) return a.ks == 1 ? "conv1x1_split_bf16x3_mfma" : "conv3x3s1_split_bf16x3_mfma";
-  if (a.algo == 6) return a.ks == 1 ? "conv1x1_split_f16x3_mfma" : "conv3x3s1_split_f16x3_mfma";
+  if (a.algo == 7) return a.ks == 1 ? "conv1x1_split_bf16x3_mfma" : (a.stride == 2 ? "conv3x3s2_split_bf16x3_mfma" : "conv3x3s1_split_bf16x3_mfma");
+  if (a.algo == 6) return a.ks == 1 ? "conv1x1_split_f16x3_mfma" : (a.stride == 2 ? "conv3x3s2_split_f16x3_mfma" : "conv3x3s1_split_f16x3_mfma");
   if (a.algo == 5) return "conv3x3s2_polyphase_mfma_f32";
   if (a.algo == 4) return "conv3x3s1_wino2x4_mfma_f32";
   if (a.algo == 3) return "conv3x3s1_wino2d_lds_mfma_f32";

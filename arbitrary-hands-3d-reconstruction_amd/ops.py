@@ -46,8 +46,8 @@ def conv2d(x, weight, bias=None, stride=1, relu=False, residual=None, groups=1, 
     b = np.zeros(cout_t, np.float32) if bias is None else (
         bias.detach().cpu().numpy() if hasattr(bias, 'detach') else np.asarray(bias))
     if algo in ('split16', 'split_bf16'):
-        if k not in (1, 3) or stride != 1:
-            raise ValueError('the split-operand kernels are for 3x3 and 1x1 stride-1 convolutions')
+        if k not in (1, 3) or stride not in (1, 2) or (k == 1 and stride != 1):
+            raise ValueError('the split-operand kernels are for 3x3 (stride 1 or 2) and 1x1 stride-1 convolutions')
         tr = None
     elif algo == 'polyphase2':
         if k != 3 or stride != 2:

@@ -291,9 +291,19 @@ def polyphase2_ok(cin, cout, ho, wo):
 
 # Split-operand 16-bit program ('fp16x3': fp32 storage, every operand of the eligible convolutions split into two f16
 # numbers, three products per MAC on the 16-bit matrix pipe with fp32 accumulation - csrc/conv_x3.inc, algo 6).
+# 3x3 stride-2 layers of the split-operand programs on conv_x3s2_kernel (round 6); ACRMI_X3_STRIDE2=0 keeps the fp32 polyphase
+# kernel for them (A/B runs)
+SPLIT16_STRIDE2 = __import__('os').environ.get('ACRMI_X3_STRIDE2', '1') != '0'
+
+
 def split16_ok(k, stride, cin, cout, ho, wo):
-    """conv_x3_kernel (3x3) / conv_x3p_kernel (1x1) takes the layer (csrc/conv_x3.inc x3_ok, conv_x3p.inc x3p_ok)."""
-    if not (stride == 1 and cin % 32 == 0 and cin >= 32 and cout % 32 == 0):
+    """conv_x3_kernel (3x3) / conv_x3p_kernel (1x1) / conv_x3s2_kernel (3x3 stride 2) takes the layer (csrc/conv_x3.inc x3_ok,
+    conv_x3p.inc x3p_ok, conv_x3s2.inc x3s2_ok)."""
+    if not (cin % 32 == 0 and cin >= 32 and cout % 32 == 0):
+        return False
+    if stride == 2:
+        return SPLIT16_STRIDE2 and k == 3 and ho % 8 == 0 and wo % 32 == 0
+    if stride != 1:
         return False
     return (k == 3 and ((ho % 8 == 0 and wo % 32 == 0) or (ho % 16 == 0 and wo % 16 == 0))) or (
         k == 1 and ho * wo > 0 and (ho * wo) % 256 == 0)
@@ -536,13 +546,16 @@ class Program(object):
         return op
 
     def conv(self, name, src, wb_list, k, stride, relu, out=None, out_c=None, in_coff=0, out_coff=0, res=None,
-             res_coff=0, cin=None, bias_buf=None, bias_map=None, terms=None, dual=None):
+             res_coff=0, cin=None, bias_buf=None, bias_map=None, terms=None, dual=None, fp32_kernel=False):
         """wb_list: [(w, b)] one entry per group (all same shape).  bias_map: [Ho,Wo,round4(groups*Cout)] added to every
         frame before the ReLU (ACRMI_CONV_BIAS_MAP; fp32 programs, no residual).  terms: [(buf, shift)] up to three extra
         residual maps at 1 / 2^shift of the output size, added behind `res` before the ReLU in this order (fp32 3x3
         stride-2 convolutions: the HR fuse sum in the epilogue of the x0 downsampling chain, fuse_epilogue_ok).
         dual: (out2, [(buf, shift)]) - ACRMI_CONV_DUAL: `out` gets the convolution as usual, out2 = relu(out + the terms) - the
-        full-resolution HR fuse sum written by conv_wino3_kernel's store waves (algo 3 only, fuse0_ok)."""
+        full-resolution HR fuse sum written by conv_wino3_kernel's store waves (algo 3 only, fuse0_ok).
+        fp32_kernel: keep the fp32 kernel in a split-operand program (the last convolution of an x0 downsampling chain: it
+        is the HR fuse host where fuse_epilogue_ok, on conv_pp2_kernel - and stays on that kernel where it is not, so that
+        both lowerings compute the same bits)."""
         h, w_, _ = self.dims(src)
         cout, cin_w = wb_list[0][0].shape[:2]
         cin = cin_w if cin is None else cin
@@ -579,8 +592,9 @@ class Program(object):
             packed = [pack_conv_h16(w, b, self.dt) for (w, b) in wb_list]
             w_off = self.blob.add16(np.concatenate([p[0] for p in packed]))
         else:
+            # (a stride-2 conv that hosts HR fuse terms keeps the polyphase kernel: conv_x3s2_kernel has no extra residual maps)
             algo = 2 if slices > 1 else conv_algo(k, stride, cin, cout, len(wb_list), ho, wo, bias_buf is not None, self.wino24,
-                                                    self.split16)
+                                                    False if ((terms or fp32_kernel) and stride == 2) else self.split16)
             if algo in (6, 7):
                 packed = [pack_conv_x3(wb_list, DT_BF16 if algo == 7 else DT_F16)]      # (one power-of-two weight scale for the op: trailing float)
             elif algo == 3:
@@ -629,6 +643,8 @@ class Program(object):
             fam = 'conv_wino24b_kernel'
         if algo in (6, 7) and k == 1:
             fam = 'conv_x3p_kernel'
+        if algo in (6, 7) and stride == 2:
+            fam = 'conv_x3s2_kernel'
         if (algo == 0 and k == 1 and stride == 1 and cin % 32 == 0 and cout % 32 == 0 and (ho * wo) % 256 == 0 and
                 (WINOGRAD_24 if self.wino24 is None else self.wino24) and
                 (ho * wo // 256) * 64 * ng * ((cout // 32) // (2 if cout % 64 == 0 else 1)) >= 512):
@@ -808,6 +824,8 @@ class Program(object):
             for k in range(i - j):
                 last = k == i - j - 1
                 kw = dict(terms=hosted) if (last and hosted) else {}
+                if last and j == 0:
+                    kw['fp32_kernel'] = True      # the x0 chain's last conv: the fuse host's kernel in every lowering (Program.conv)
                 t2 = self.conv_bn(t, '%s.%d.0' % (f, k), '%s.%d.1' % (f, k), 3, 2, (not last) or bool(hosted), padded=True, **kw)
                 if t is not xs[j]:
                     self.release(t)

@@ -185,7 +185,7 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
                                    bufs_[o.out_buf][0] * bufs_[o.out_buf][1] * o.cout * o.groups * esz(o.out_buf) *
                                    (2 if o.res_buf >= 0 else 1))
         r = {'value': round(B * steps / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
-             'dtype': ('f32 storage; 3x3 and 1x1 stride-1 layers: operands split into %s hi + lo, 3 products per MAC on '
+             'dtype': ('f32 storage; 3x3 (stride 1; stride 2 outside the HR fuse hosts) and 1x1 stride-1 layers: operands split into %s hi + lo, 3 products per MAC on '
                        'v_mfma_f32_32x32x16_%s, f32 accumulate; other ops as the fp32 program' % (({'fp16x3': 'f16', 'bf16x3': 'bf16'}[prec],) * 2)
                        if prec.endswith('x3') else
                        {'fp16': 'f16', 'bf16': 'bf16'}[prec] + ' storage, f32 accumulate (v_mfma_f32_32x32x16)'),

@@ -388,6 +388,55 @@ def test_conv2d_split_f16_operands(ops, case):
     assert errs['split_bf16'] < 5e-4, errs      # 16-bit operands: 2^-16 relative per product
 
 
+X3S2_CASES = [
+    # (B, Cin, Cout, H, W (input), groups, relu, residual kind: 0 none / 1 per frame / 2 one map for every frame, frame_bias)
+    (2, 64, 64, 64, 128, 1, True, 0, False),       # stem conv2 shape: two chunks, two tile columns, four tile rows
+    (20, 32, 64, 32, 64, 1, False, 0, False),      # fuse chain 32 -> 64: single-chunk items, 40 of them x 1 tile
+    (3, 32, 32, 16, 64, 1, False, 0, False),       # fuse chain 32 -> 32: one n-tile per wave, one tile per frame (all borders)
+    (2, 128, 256, 16, 64, 1, True, 1, False),      # transition3-like: four chunks, four n-blocks, per-frame residual
+    (2, 32, 512, 32, 128, 1, True, 2, False),      # tower entry: eight n-blocks, the position-bias map as a residual for every frame
+    (2, 64, 128, 48, 192, 1, False, 0, True),      # interior tile columns and rows, per-frame bias rows
+    (1, 128, 192, 16, 64, 2, True, 1, False),      # two groups of 64 -> 96 (one n-tile per wave, three n-blocks each)
+]
+
+
+@pytest.mark.parametrize('case', X3S2_CASES, ids=lambda c: 'x3s2_B%d_%dto%d_%dx%d_g%d_r%d_fb%d' % (c[:6] + (c[7], int(c[8]))))
+def test_conv2d_stride2_split_f16_operands(ops, case):
+    """conv_x3s2_kernel (3x3 stride 2, fp32 storage, operands split into hi + lo f16 / bf16, de-interleaved patch columns, one
+    16-channel step per plane buffer) vs an fp64 direct convolution and vs the fp32 polyphase kernel on the same data.
+    Channel slices of wider buffers; neighbours untouched."""
+    B, cin, cout, H, W, groups, relu, res_kind, use_fb = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 270)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin // groups, 3, 3, generator=g) / np.sqrt(cin // groups * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    fb = torch.randn(B, cout, generator=g) if use_fb else None
+    ref = F.conv2d(x.double(), w.double(), None if use_fb else b.double(), 2, 1, 1, groups)
+    if use_fb:
+        ref = ref + fb[:, :, None, None].double()
+    res = None
+    if res_kind:
+        res = torch.randn((B if res_kind == 1 else 1, cout, H // 2, W // 2), generator=g)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xin = torch.full((B, H, W, cin + 8), 3.0, device='cuda')            # input in channels 4.. of a wider buffer
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1).cuda()
+    errs = {}
+    for algo in ('split16', 'split_bf16', 'polyphase2'):
+        dst = torch.full((B, H // 2, W // 2, cout + 16), 7.0, device='cuda')     # output into channels 8..
+        ops.conv2d(xin, w, None if use_fb else b, stride=2, relu=relu, groups=groups, cin=cin // groups, in_coff=4, algo=algo,
+                   out=dst, out_coff=8, residual=None if res is None else ops.to_nhwc(res),
+                   frame_bias=None if fb is None else fb.cuda())
+        torch.cuda.synchronize()
+        got = dst[..., 8:8 + cout].permute(0, 3, 1, 2).cpu()
+        errs[algo] = (got.double() - ref).abs().max().item()
+        assert (dst[..., :8] == 7).all() and (dst[..., 8 + cout:] == 7).all(), algo
+    assert errs['split16'] < 2e-5, errs
+    assert errs['split16'] < 4 * errs['polyphase2'] + 1e-6, errs
+    assert errs['split_bf16'] < 5e-4, errs      # 16-bit operands: 2^-16 relative per product
+
+
 X3P_CASES = [
     # (B, Cin, Cout, H, W, groups, relu, residual kind: 0 none / 1 per frame, frame_bias)
     (2, 64, 256, 16, 16, 1, True, 1, False),       # one item per frame, four n-blocks (layer1's conv3: residual + ReLU)

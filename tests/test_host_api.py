@@ -323,11 +323,15 @@ def test_split16_and_pack_conv_x3_layout():
     assert packer.conv_algo(1, 1, 256, 64, 1, 10, 10, split16=True) == 0 and packer.conv_algo(1, 2, 256, 64, 1, 64, 64, split16=True) == 0
     assert packer.conv_algo(3, 1, 64, 64, 1, 16, 16, split16=True) == 6 and packer.conv_algo(3, 1, 16, 64, 1, 64, 64, split16=True) == 2
     assert packer.conv_algo(3, 1, 64, 64, 1, 24, 16, split16=True) == 2
+    # 3x3 stride 2 (round 6, conv_x3s2.inc): onto maps of 8x32-pixel tiles; the others keep the polyphase kernel
+    assert packer.conv_algo(3, 2, 64, 64, 1, 128, 128, split16=True) == 6 and packer.conv_algo(3, 2, 64, 128, 1, 32, 32, split16='bf16') == 7
+    assert packer.conv_algo(3, 2, 128, 256, 1, 16, 16, split16=True) == 5 and packer.conv_algo(3, 2, 16, 64, 1, 64, 64, split16=True) == 5
 
 
 def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
-    """'fp16x3' lowers to the SAME op list, buffers and biases as 'fp32' - only the eligible 3x3 and 1x1 stride-1 convolutions
-    change their kernel (algo 6) and weight packing."""
+    """'fp16x3' lowers to the SAME op list, buffers and biases as 'fp32' - only the eligible 3x3 (stride 1, and stride 2 where the
+    convolution is not a HR fuse host / the last link of an x0 chain) and 1x1 stride-1 convolutions change their kernel
+    (algo 6) and weight packing."""
     packer, L = pkg('packer'), pkg('_lib')
     saved = packer.FUSE_FULLRES      # (the full-resolution fuse sum as conv_wino3's second output exists in the fp32 program only:
     packer.FUSE_FULLRES = False      #  branch 0's convolutions are conv_x3 launches in the split-operand program)
@@ -337,16 +341,20 @@ def test_fp16x3_program_is_the_fp32_program_with_other_kernels(synth_sd):
         packer.FUSE_FULLRES = saved
     px3 = packer.lower(synth_sd, precision='fp16x3', point_heads=False)
     assert px3['bufs'] == p32['bufs'] and len(px3['ops']) == len(p32['ops'])
-    n6 = 0
+    n6 = n6s2 = 0
     for a, b in zip(p32['ops'], px3['ops']):
         assert (a.kind, a.in_buf, a.out_buf, a.res_buf, a.cin, a.cout, a.ksize, a.stride, a.groups) == (
             b.kind, b.in_buf, b.out_buf, b.res_buf, b.cin, b.cout, b.ksize, b.stride, b.groups)
         if b.kind == L.OP_CONV and (b.flags & 7) == 6:
             n6 += 1
-            assert b.stride == 1 and ((b.ksize == 3 and (a.flags & 7) in (3, 4)) or (b.ksize == 1 and (a.flags & 7) == 0))
+            if b.stride == 2:
+                n6s2 += 1
+                assert b.ksize == 3 and (a.flags & 7) == 5 and b.nterms == 0 and a.flags - 5 == b.flags - 6      # (e.g. the bias-map flag)
+            else:
+                assert b.stride == 1 and ((b.ksize == 3 and (a.flags & 7) in (3, 4)) or (b.ksize == 1 and (a.flags & 7) == 0))
         else:
             assert a.flags == b.flags
-    assert n6 >= 190
+    assert n6 >= 190 and n6s2 >= 20
     with pytest.raises(ValueError):
         packer.lower(synth_sd, precision='fp8')
 
@@ -372,7 +380,9 @@ def test_x3_weight_scale_sits_where_the_kernel_reads_it_for_every_op(synth_sd, p
         assert blob[pos] == want, (info['name'], float(blob[pos]), float(want))
         seen += 1
         point += op.mode == L.MODE_POINT
-    assert seen >= 190 and point == 4      # the four center-tower convs of the point-heads variant carry their own packs
+    # the four center-tower convs of the point-heads variant carry their own packs; so does its 32 -> 128 stride-2 tower entry (a
+    # split-operand launch since round 6, conv_x3s2.inc)
+    assert seen >= 190 and point == 5
 
 
 @pytest.mark.parametrize('lowering', ['large', 'small', 'fp16x3', 'fp16'])

@@ -125,7 +125,7 @@ def main():
                 wino = 4      # (incl. Cin = 32 shapes: the four-wave frame's single-chunk kernels, also where the program keeps conv_wino3)
         if args.pp2 and k == 3 and stride == 2 and packer.polyphase2_ok(cing, coutg, H // 2, W // 2):
             wino = 5
-        x3 = args.x3 and packer.split16_ok(k, stride, cing, coutg, H, W)
+        x3 = args.x3 and packer.split16_ok(k, stride, cing, coutg, Ho, Wo)
         if wino and args.wino3 and groups == 1 and cin <= 32 and cout == 32:
             wino = 3
             packed = [packer.pack_wino3(w.astype(np.float64), np.zeros(coutg, np.float32))]
