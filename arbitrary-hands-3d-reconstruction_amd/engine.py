@@ -67,8 +67,8 @@ class Engine(object):
         """acr/utils.py:1153-1168 (load_model): reference-format checkpoint -> resident packed weights.
         keep_taps: see packer.lower (backbone taps stay readable through `buffer(program['taps'][name], B)`).
         precision: 'fp32' | 'fp16' | 'bf16' (args().model_precision, acr/config.py:96; packer.lower) | 'fp16x3' / 'bf16x3' (fp32
-        storage, operands split into two f16 / bf16 numbers on the 16-bit matrix pipe for the 3x3 and 1x1 stride-1 layers:
-        csrc/conv_x3.inc).  'fp16x3' has the f16 RANGE: every activation must stay within |x| <= 65504 - a checkpoint that
+        storage, operands split into two f16 / bf16 numbers on the 16-bit matrix pipe for the 3x3 (stride 1, stride 2 outside the HR
+        fuse hosts) and 1x1 stride-1 layers: csrc/conv_x3.inc, conv_x3p.inc, conv_x3s2.inc).  'fp16x3' has the f16 RANGE: every activation must stay within |x| <= 65504 - a checkpoint that
         exceeds it makes the affected calls return NaN slots / meshes and `check_range()` raise AcrmiRangeError (the
         host-facing API calls it); 'bf16x3' has fp32's range at 16-bit operand precision (8e-6 m instead of 1e-6 m on the
         bench frames)

@@ -146,7 +146,7 @@ def reduced_precision(sd, tables, frames, B, steps, warmup, oracle, local_rank, 
     its bf16 twin as 16-bit programs (packer.lower) on the same frames, same K steps, two contexts in turn like the
     headline; `parity` = against the fp32 oracle (what 16-bit storage costs), not against a 16-bit reference (none
     exists: autocast is CUDA-only).  'fp16x3' = fp32 STORAGE with split operands on the 16-bit matrix pipe (csrc/conv_x3.inc:
-    x = hi + lo in f16, three products per MAC, fp32 accumulation) for the 3x3 stride-1 layers it takes; every other op is
+    x = hi + lo in f16, three products per MAC, fp32 accumulation) for the 3x3 and 1x1 layers it takes; every other op is
     the fp32 program's."""
     res = {}
     for prec in precisions:
