@@ -68,6 +68,12 @@ def cpu_baseline(sd, tables):
     from oracle import acr_net, decode as odec, mano as omano
     frames = torch.from_numpy(pkg('synth').make_frames(8, seed=3))
     model, phys, logical = _cpu_model()
+    # what else the box's host side was doing (round 6: 4.8 and 9.2 frames/s from the same code and CPU model on two boxes)
+    try:
+        load0 = os.getloadavg()
+        avail = len(os.sched_getaffinity(0))
+    except (OSError, AttributeError):
+        load0, avail = None, None
 
     last = {}
 
@@ -117,6 +123,8 @@ def cpu_baseline(sd, tables):
             'physical_cores_note': 'n = all %s physical cores (SURVEY.md 8d(ii)), batch 8, one timed pass after a first-touch pass' % nphys,
             'batch1_fps': round(1 / res[1], 3), 'batch8_fps': round(8 / res[8], 3),
             'thread_probe_s_per_batch8': {str(k): round(v, 3) for k, v in probe.items()},
+            'host': {'loadavg_before': [round(x, 2) for x in load0] if load0 else None, 'cpus_available_to_this_process': avail,
+                     'note': 'a GPU box\'s host cores are shared: this figure moves with the other tenants, the GPU figures do not'},
             'sample': 'oracle/ (torch-CPU fp32 restatement of the reference) on the same synthetic 512x512 frames; batch 1 '
                       'and batch 8, 2 warm-ups + median of 5 passes each at %d threads (best of %s, 2 timed passes per count); value = '
                       'the better of the two (batch %d)' % (best, sorted(probe), 1 if b1 >= b8 else 8)}
