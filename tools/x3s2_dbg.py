@@ -1,3 +1,9 @@
+"""conv_x3s2_kernel (3x3 stride 2, split operands) against an fp64 direct convolution on a few shapes, printing WHERE the bad
+elements sit (channels / rows / columns) - the tool that separated the one-n-tile multi-chunk f16 build with 584 bytes of
+scratch (wrong sums) from its bf16 twin (right) in round 6 (GPU box only):
+
+    python tools/x3s2_dbg.py
+"""
 import importlib, sys, os
 import numpy as np, torch
 import torch.nn.functional as F
