@@ -397,6 +397,9 @@ X3S2_CASES = [
     (2, 32, 512, 32, 128, 1, True, 2, False),      # tower entry: eight n-blocks, the position-bias map as a residual for every frame
     (2, 64, 128, 48, 192, 1, False, 0, True),      # interior tile columns and rows, per-frame bias rows
     (1, 128, 192, 16, 64, 2, True, 1, False),      # two groups of 64 -> 96 (one n-tile per wave, three n-blocks each)
+    (2, 256, 32, 16, 64, 1, True, 0, False),       # one n-tile per wave, eight chunks (the instantiation whose first f16 build - 584 bytes of scratch - summed wrongly)
+    (3, 64, 32, 32, 128, 1, False, 1, False),      # ... two chunks, several tiles per frame, per-frame residual
+    (5, 96, 64, 16, 64, 1, True, 0, False),        # three chunks (an odd count: a chunk = two 16-channel steps), two n-tiles per wave
 ]
 
 
